@@ -1,0 +1,180 @@
+/*
+ * lsdsort.h -- C-ABI of the MI355X-native LSD radix sort (liblsdsort.so).
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  Every entry returns 0
+ * (LSDSORT_OK) or a negative lsdsort_status; nothing here aborts the process (the reference
+ * crashes on any error: CUDA_CALL, LSDRadixSort/CudaUtils.h:7-8; MYASSERT, Utils.h:6-15).
+ *
+ * What each entry replaces in the reference (paths relative to /root/reference/, ".cu" =
+ * LSDRadixSort/LSDRadixSort.cu) is cited at its declaration.  The reference has no
+ * sort(uint32_t*, size_t) symbol; lsdsort_u32 is defined as "what
+ * TestGPULSDRadixSort does between .cu:1001 and .cu:1005, minus RNG and checking".
+ *
+ * There is NO CPU fallback behind this ABI: without a usable gfx950 device every compute
+ * entry returns LSDSORT_ERR_NO_DEVICE.  The CPU legs of the reference (std::sort .cu:97,
+ * CPU LSD .cu:25-69) live in oracle/ as test infrastructure only.
+ */
+#ifndef LSDSORT_H
+#define LSDSORT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(LSDSORT_BUILD)
+#define LSDSORT_API __attribute__((visibility("default")))
+#else
+#define LSDSORT_API
+#endif
+
+typedef enum lsdsort_status {
+    LSDSORT_OK = 0,
+    LSDSORT_ERR_INVALID_ARG = -1,  /* null pointer with n > 0, bad radix_bits, bad enum          */
+    LSDSORT_ERR_NO_DEVICE = -2,    /* no HIP device / not gfx950; also num_gpus == 0 (no CPU path) */
+    LSDSORT_ERR_HIP = -3,          /* a HIP runtime call failed; see lsdsort_last_hip_error()    */
+    LSDSORT_ERR_WORKSPACE = -4,    /* workspace null, misaligned or smaller than required        */
+    LSDSORT_ERR_TOO_LARGE = -5,    /* n above LSDSORT_MAX_KEYS                                   */
+    LSDSORT_ERR_UNSUPPORTED = -6,  /* valid request this build does not serve (e.g. num_gpus>1)  */
+    LSDSORT_ERR_DEVICE_FAULT = -7  /* a kernel reported a bounded-spin timeout (see below)       */
+} lsdsort_status;
+
+/* Largest n any entry accepts: the chained tile prefix keeps 30 value bits per word.  The
+ * reference stops at int count < 2^31 (.cu:839) and in practice at 2^30 (.cu:1033-1042). */
+#define LSDSORT_MAX_KEYS ((size_t)0x3fffffffu)
+
+/* Which pass structure runs on the device. */
+typedef enum lsdsort_algorithm {
+    /* default: one read of all keys for every digit histogram, one scan of the digit counts,
+     * then per pass ONE rank-and-scatter kernel whose per-tile bases come from a chained
+     * (decoupled look-back) scan over tiles.  4*(2P+1) bytes per key. */
+    LSDSORT_ALGO_ONESWEEP = 0,
+    /* the reference's own stage structure (GPULSDRadixSort, .cu:839-910): per pass
+     * BuildHistogram -> local/global offsets -> rank-and-scatter as separate kernels with
+     * the [tile][digit] tables in memory.  12 bytes per key per pass.  Same results. */
+    LSDSORT_ALGO_STAGED = 1
+} lsdsort_algorithm;
+
+/* ---- host-pointer entries ------------------------------------------------------------- */
+
+/* sort(uint32_t* keys, size_t n) of BASELINE.json's north_star: host pointer, in place,
+ * ascending.  Replaces the alloc / H2D / GPULSDRadixSort / D2H sequence of
+ * TestGPULSDRadixSort, .cu:966-1005.  Blocking.  radix 8, current HIP device. */
+LSDSORT_API int lsdsort_u32(uint32_t* keys, size_t n);
+
+/* Same with the radix width (1, 2, 4 or 8 -- the reference's sweep `rs`, .cu:1055-1062) and
+ * a GPU count.  num_gpus must be 1: 0 (the "CPU path") returns LSDSORT_ERR_NO_DEVICE and
+ * more than one GPU is served one-process-per-GPU by lsdsort_msb_partition_u32_device plus
+ * the caller's RCCL communicator, so >1 returns LSDSORT_ERR_UNSUPPORTED. */
+LSDSORT_API int lsdsort_u32_ex(uint32_t* keys, size_t n, int radix_bits, int num_gpus);
+
+/* Key/value form, stable by key (BASELINE.json configs[4]); no reference counterpart. */
+LSDSORT_API int lsdsort_pairs_u32(uint32_t* keys, uint32_t* vals, size_t n);
+
+/* ---- device-resident entries (the timed path) ---------------------------------------- */
+
+/* Bytes of device workspace the device entries need for (n, radix_bits, pairs?, algorithm).
+ * Replaces the reference's d_b + d_h + d_block_sums sizing, .cu:919-930 and
+ * GetGPUPrefixSumBlockSumsCount .cu:265-276.  Returns 0 for invalid arguments. */
+LSDSORT_API size_t lsdsort_workspace_bytes(size_t n, int radix_bits, int pairs);
+LSDSORT_API size_t lsdsort_workspace_bytes_ex(size_t n, int radix_bits, int pairs, int algorithm);
+
+/* Replaces GPULSDRadixSort(a, b, h, block_sums, d, grid, block, ...), .cu:839-910: device
+ * pointers, result in d_keys (the reference's `a`; the pass count is even), stream-ordered
+ * on hip_stream (a hipStream_t; NULL = the null stream), does not synchronise.  The
+ * workspace (256-byte aligned) holds the ping-pong buffer (`b`) and every table (`h`,
+ * `block_sums`); nothing is allocated or freed inside, so the call can be graph-captured. */
+LSDSORT_API int lsdsort_u32_device(uint32_t* d_keys, void* d_workspace, size_t workspace_bytes,
+                                   size_t n, int radix_bits, void* hip_stream);
+LSDSORT_API int lsdsort_pairs_u32_device(uint32_t* d_keys, uint32_t* d_vals, void* d_workspace,
+                                         size_t workspace_bytes, size_t n, int radix_bits,
+                                         void* hip_stream);
+/* Same with the pass structure chosen explicitly; d_vals may be NULL (keys only). */
+LSDSORT_API int lsdsort_u32_device_ex(uint32_t* d_keys, uint32_t* d_vals, void* d_workspace,
+                                      size_t workspace_bytes, size_t n, int radix_bits,
+                                      int algorithm, void* hip_stream);
+
+/* After the stream has drained: LSDSORT_OK, or LSDSORT_ERR_DEVICE_FAULT if a kernel of the
+ * last sort on this workspace gave up a bounded spin (never expected; the output is then
+ * undefined).  Synchronises hip_stream. */
+LSDSORT_API int lsdsort_check_device(void* d_workspace, void* hip_stream);
+
+/* Per-kernel device times of one sort, by hipEvent on hip_stream (the reference times only
+ * the whole sort, .cu:1002-1004).  Blocking.  Stages beyond `passes` are zero. */
+#define LSDSORT_MAX_PASSES 32
+typedef struct lsdsort_timing {
+    float total_ms;       /* first kernel start to last kernel end                         */
+    float clear_ms;       /* workspace control words + tile-status memset                   */
+    float histogram_ms;   /* stage 1 (onesweep: all digits in one read; staged: summed)     */
+    float scan_ms;        /* stage 2 (digit-count scan / tile offset tables)                */
+    float scatter_ms[LSDSORT_MAX_PASSES]; /* stage 3, one entry per pass                    */
+    int passes;
+    int tile_keys;        /* keys per rank-and-scatter tile                                 */
+    int tiles;
+} lsdsort_timing;
+LSDSORT_API int lsdsort_u32_device_timed(uint32_t* d_keys, uint32_t* d_vals, void* d_workspace,
+                                         size_t workspace_bytes, size_t n, int radix_bits,
+                                         int algorithm, void* hip_stream, lsdsort_timing* out);
+
+/* ---- stage entries (device pointers, stream-ordered) ---------------------------------- */
+/* The three stages of a pass as separate calls, for stage-level parity and the histogram /
+ * scan micro-benchmarks (counterparts of TestBuildHistogram .cu:704 and TestGPUPrefixSum
+ * .cu:304).  Tables are block-major [tiles][2^radix_bits] exactly like the reference's `h`. */
+
+/* Keys per tile of the stage entries for this radix (the reference's `block`). */
+LSDSORT_API size_t lsdsort_tile_keys(int radix_bits);
+
+/* Replaces BuildHistogramsKernel, .cu:660-702 (launch .cu:850): d_hist[t][d] = number of
+ * keys of tile t whose digit `bit_group` equals d. */
+LSDSORT_API int lsdsort_tile_histograms_u32_device(const uint32_t* d_keys, size_t n, int radix_bits,
+                                                   int bit_group, uint32_t* d_hist, void* hip_stream);
+
+/* Replaces .cu:862-895 (D2D copy, BlockPrefixSumKernel as local scan, two transposes,
+ * GPUPrefixSum + AddBlockSumsKernel): from the counts in d_hist writes d_local (per-tile
+ * exclusive scan) and d_global (digit-major exclusive scan, stored block-major).
+ * d_scratch holds lsdsort_tile_offsets_scratch_bytes(tiles, radix_bits) bytes. */
+LSDSORT_API size_t lsdsort_tile_offsets_scratch_bytes(size_t tiles, int radix_bits);
+LSDSORT_API int lsdsort_tile_offsets_u32_device(const uint32_t* d_hist, uint32_t* d_local,
+                                                uint32_t* d_global, size_t tiles, int radix_bits,
+                                                void* d_scratch, void* hip_stream);
+
+/* Replaces LSDRadixSortKernel, .cu:795-837 (launch .cu:902): stable rank inside each tile,
+ * dst = rank - local[d] + global[d] (.cu:833), scatter.  d_vals_in/out may be NULL. */
+LSDSORT_API int lsdsort_rank_scatter_u32_device(const uint32_t* d_in, uint32_t* d_out,
+                                                const uint32_t* d_vals_in, uint32_t* d_vals_out,
+                                                const uint32_t* d_global, size_t n, int radix_bits,
+                                                int bit_group, void* hip_stream);
+
+/* One read of all keys -> all 32/radix_bits digit histograms, d_hist[g][d] (uint32). */
+LSDSORT_API int lsdsort_digit_histograms_u32_device(const uint32_t* d_keys, size_t n, int radix_bits,
+                                                    uint32_t* d_hist, void* hip_stream);
+
+/* ---- multi-GPU building block (one process per GPU) ----------------------------------- */
+/* Stable partition of this rank's shard by the top msb_bits bits (0..3): d_out holds bucket
+ * 0, bucket 1, ... contiguously, d_counts[b] (uint64, 2^msb_bits entries) their sizes.  The
+ * caller exchanges buckets with its RCCL communicator (all-to-all over xGMI) and then runs
+ * lsdsort_u32_device on what it received.  New work; the reference is single-GPU. */
+LSDSORT_API size_t lsdsort_msb_partition_workspace_bytes(size_t n, int msb_bits);
+LSDSORT_API int lsdsort_msb_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size_t n,
+                                                 int msb_bits, uint64_t* d_counts, void* d_workspace,
+                                                 size_t workspace_bytes, void* hip_stream);
+
+/* ---- misc ----------------------------------------------------------------------------- */
+LSDSORT_API const char* lsdsort_strerror(int status);
+/* hipError_t of the most recent failed HIP call on this thread (0 if none) and its text. */
+LSDSORT_API int lsdsort_last_hip_error(void);
+LSDSORT_API const char* lsdsort_last_hip_error_string(void);
+/* "lsdsort <version> gfx950 hip <runtime>" */
+LSDSORT_API const char* lsdsort_version(void);
+/* Number of usable devices (gfx950) visible to this process; 0 if none.  Never fails. */
+LSDSORT_API int lsdsort_device_count(void);
+/* Runtime tuning knob for experiments: selects among the compiled tile shapes (see
+ * DESIGN.md); -1 restores the default.  Returns LSDSORT_ERR_INVALID_ARG if unknown. */
+LSDSORT_API int lsdsort_set_tile_config(int radix_bits, int config_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSDSORT_H */

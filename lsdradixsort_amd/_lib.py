@@ -1,0 +1,86 @@
+"""ctypes binding of liblsdsort.so (include/lsdsort.h).
+
+The HIP library is the product; there is no Python or CPU fallback.  If the shared object is
+missing or fails to load, importing this module's ``lib()`` raises immediately and loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblsdsort.so")
+
+c_u32p = ctypes.c_void_p   # device or host addresses are passed as integers
+c_size = ctypes.c_size_t
+c_int = ctypes.c_int
+
+LSDSORT_MAX_PASSES = 32
+
+
+class LsdsortTiming(ctypes.Structure):
+    """Mirror of ``lsdsort_timing`` (include/lsdsort.h)."""
+
+    _fields_ = [
+        ("total_ms", ctypes.c_float),
+        ("clear_ms", ctypes.c_float),
+        ("histogram_ms", ctypes.c_float),
+        ("scan_ms", ctypes.c_float),
+        ("scatter_ms", ctypes.c_float * LSDSORT_MAX_PASSES),
+        ("passes", ctypes.c_int),
+        ("tile_keys", ctypes.c_int),
+        ("tiles", ctypes.c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/lsdsort.h declares
+SIGNATURES = {
+    "lsdsort_u32": (c_int, [c_u32p, c_size]),
+    "lsdsort_u32_ex": (c_int, [c_u32p, c_size, c_int, c_int]),
+    "lsdsort_pairs_u32": (c_int, [c_u32p, c_u32p, c_size]),
+    "lsdsort_workspace_bytes": (c_size, [c_size, c_int, c_int]),
+    "lsdsort_workspace_bytes_ex": (c_size, [c_size, c_int, c_int, c_int]),
+    "lsdsort_u32_device": (c_int, [c_u32p, ctypes.c_void_p, c_size, c_size, c_int, ctypes.c_void_p]),
+    "lsdsort_pairs_u32_device": (c_int, [c_u32p, c_u32p, ctypes.c_void_p, c_size, c_size, c_int, ctypes.c_void_p]),
+    "lsdsort_u32_device_ex": (c_int, [c_u32p, c_u32p, ctypes.c_void_p, c_size, c_size, c_int, c_int, ctypes.c_void_p]),
+    "lsdsort_check_device": (c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "lsdsort_u32_device_timed": (c_int, [c_u32p, c_u32p, ctypes.c_void_p, c_size, c_size, c_int, c_int,
+                                         ctypes.c_void_p, ctypes.POINTER(LsdsortTiming)]),
+    "lsdsort_tile_keys": (c_size, [c_int]),
+    "lsdsort_tile_histograms_u32_device": (c_int, [c_u32p, c_size, c_int, c_int, c_u32p, ctypes.c_void_p]),
+    "lsdsort_tile_offsets_scratch_bytes": (c_size, [c_size, c_int]),
+    "lsdsort_tile_offsets_u32_device": (c_int, [c_u32p, c_u32p, c_u32p, c_size, c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "lsdsort_rank_scatter_u32_device": (c_int, [c_u32p, c_u32p, c_u32p, c_u32p, c_u32p, c_size, c_int, c_int,
+                                                ctypes.c_void_p]),
+    "lsdsort_digit_histograms_u32_device": (c_int, [c_u32p, c_size, c_int, c_u32p, ctypes.c_void_p]),
+    "lsdsort_msb_partition_workspace_bytes": (c_size, [c_size, c_int]),
+    "lsdsort_msb_partition_u32_device": (c_int, [c_u32p, c_u32p, c_size, c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                 c_size, ctypes.c_void_p]),
+    "lsdsort_strerror": (ctypes.c_char_p, [c_int]),
+    "lsdsort_last_hip_error": (c_int, []),
+    "lsdsort_last_hip_error_string": (ctypes.c_char_p, []),
+    "lsdsort_version": (ctypes.c_char_p, []),
+    "lsdsort_device_count": (c_int, []),
+    "lsdsort_set_tile_config": (c_int, [c_int, c_int]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load liblsdsort.so and bind every entry point.  Raises if the HIP build is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(`make -C lsdradixsort_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "lsdradixsort_amd has no CPU fallback."
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError if the export is missing
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = L
+    return _lib

@@ -1,0 +1,219 @@
+"""Host-side mirror of the reference's sort path over the C-ABI (include/lsdsort.h).
+
+Names follow the reference's own (``LSDRadixSort/LSDRadixSort.cu``): ``GPULSDRadixSort``
+(.cu:839), ``BuildHistograms`` (.cu:660), ``LSDRadixSortKernel`` -> ``rank_scatter`` (.cu:795).
+PyTorch is plumbing only: device memory (``torch.int32`` tensors holding the uint32 bit
+patterns) and the current HIP stream.  All computation happens in ``liblsdsort.so``; nothing
+here falls back to PyTorch or the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import errors
+from ._lib import LsdsortTiming, lib
+from .errors import LSDSORT_ALGO_ONESWEEP, LSDSORT_ALGO_STAGED, check
+
+__all__ = [
+    "sort", "sort_pairs", "to_device", "to_host", "workspace_bytes", "GPULSDRadixSort",
+    "GPULSDRadixSortTimed", "BuildHistograms", "BuildOffsets", "RankScatter", "DigitHistograms",
+    "MSBPartition", "tile_keys", "set_tile_config", "LSDSORT_ALGO_ONESWEEP", "LSDSORT_ALGO_STAGED",
+]
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+# ------------------------------------------------------------------------------ host-pointer entries
+def _host_u32(a: np.ndarray, name: str) -> np.ndarray:
+    if not isinstance(a, np.ndarray) or a.dtype != np.uint32 or a.ndim != 1 or not a.flags.c_contiguous:
+        raise TypeError(f"{name} must be a contiguous 1-D numpy.uint32 array")
+    if not a.flags.writeable:
+        raise TypeError(f"{name} must be writeable (sorted in place)")
+    return a
+
+
+def sort(keys: np.ndarray, radix_bits: int = 8) -> np.ndarray:
+    """``sort(uint32_t* keys, size_t n)``: host array, in place, ascending (``lsdsort_u32_ex``)."""
+    _host_u32(keys, "keys")
+    check(lib().lsdsort_u32_ex(keys.ctypes.data, keys.size, radix_bits, 1), "lsdsort_u32_ex")
+    return keys
+
+
+def sort_pairs(keys: np.ndarray, vals: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """Key/value sort, stable by key, host arrays in place (``lsdsort_pairs_u32``)."""
+    _host_u32(keys, "keys")
+    _host_u32(vals, "vals")
+    if keys.size != vals.size:
+        raise ValueError("keys and vals differ in length")
+    check(lib().lsdsort_pairs_u32(keys.ctypes.data, vals.ctypes.data, keys.size), "lsdsort_pairs_u32")
+    return keys, vals
+
+
+# ------------------------------------------------------------------------------ device plumbing
+def to_device(a: np.ndarray, device: str = "cuda"):
+    """uint32 host array -> int32 device tensor with the same bits."""
+    torch = _torch()
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return torch.from_numpy(a.view(np.int32)).to(device)
+
+
+def to_host(t) -> np.ndarray:
+    """int32 device tensor -> uint32 host array with the same bits."""
+    return t.detach().cpu().numpy().view(np.uint32)
+
+
+def _dev_i32(t, name: str):
+    torch = _torch()
+    if not isinstance(t, torch.Tensor) or t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous():
+        raise TypeError(f"{name} must be a contiguous torch.int32 CUDA tensor (uint32 bit patterns)")
+    return t
+
+
+def _stream(stream=None) -> int:
+    torch = _torch()
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return int(s.cuda_stream)
+
+
+def workspace_bytes(n: int, radix_bits: int = 8, pairs: bool = False, algorithm: int = LSDSORT_ALGO_ONESWEEP) -> int:
+    return int(lib().lsdsort_workspace_bytes_ex(n, radix_bits, int(pairs), algorithm))
+
+
+def alloc_workspace(n: int, radix_bits: int = 8, pairs: bool = False, algorithm: int = LSDSORT_ALGO_ONESWEEP,
+                    device: str = "cuda"):
+    torch = _torch()
+    nbytes = workspace_bytes(n, radix_bits, pairs, algorithm)
+    if nbytes == 0 and n > 0:
+        raise errors.LsdsortError(errors.LSDSORT_ERR_INVALID_ARG, "lsdsort_workspace_bytes_ex", "bad (n, radix_bits)")
+    # torch's caching allocator returns 512-byte aligned blocks; the ABI needs 256.
+    return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+
+
+def tile_keys(radix_bits: int) -> int:
+    return int(lib().lsdsort_tile_keys(radix_bits))
+
+
+def set_tile_config(radix_bits: int, config_id: int) -> None:
+    check(lib().lsdsort_set_tile_config(radix_bits, config_id), "lsdsort_set_tile_config")
+
+
+# ------------------------------------------------------------------------------ device-resident sort
+def GPULSDRadixSort(d_keys, r: int = 8, d_vals=None, algorithm: int = LSDSORT_ALGO_ONESWEEP, workspace=None,
+                    stream=None, check_fault: bool = False):
+    """Device-resident sort in place: the reference's ``GPULSDRadixSort(a, b, h, ...)`` (.cu:839).
+
+    ``d_keys`` (and ``d_vals``) are int32 CUDA tensors of uint32 bit patterns; the result lands
+    in ``d_keys`` like the reference's ``a``.  Stream-ordered, no synchronisation unless
+    ``check_fault`` (then the workspace fault word is read back).
+    """
+    _dev_i32(d_keys, "d_keys")
+    n = d_keys.numel()
+    pairs = d_vals is not None
+    if pairs:
+        _dev_i32(d_vals, "d_vals")
+        if d_vals.numel() != n:
+            raise ValueError("keys and vals differ in length")
+    if workspace is None:
+        workspace = alloc_workspace(n, r, pairs, algorithm, d_keys.device)
+    st = lib().lsdsort_u32_device_ex(d_keys.data_ptr(), d_vals.data_ptr() if pairs else None, workspace.data_ptr(),
+                                     workspace.numel(), n, r, algorithm, _stream(stream))
+    check(st, "lsdsort_u32_device_ex")
+    if check_fault and n:
+        check(lib().lsdsort_check_device(workspace.data_ptr(), _stream(stream)), "lsdsort_check_device")
+    return d_keys if not pairs else (d_keys, d_vals)
+
+
+def GPULSDRadixSortTimed(d_keys, r: int = 8, d_vals=None, algorithm: int = LSDSORT_ALGO_ONESWEEP, workspace=None,
+                         stream=None) -> dict:
+    """Same sort with per-kernel hipEvent times (``lsdsort_u32_device_timed``).  Blocking."""
+    _dev_i32(d_keys, "d_keys")
+    n = d_keys.numel()
+    pairs = d_vals is not None
+    if workspace is None:
+        workspace = alloc_workspace(n, r, pairs, algorithm, d_keys.device)
+    t = LsdsortTiming()
+    st = lib().lsdsort_u32_device_timed(d_keys.data_ptr(), d_vals.data_ptr() if pairs else None, workspace.data_ptr(),
+                                        workspace.numel(), n, r, algorithm, _stream(stream), ctypes.byref(t))
+    check(st, "lsdsort_u32_device_timed")
+    return {
+        "total_ms": t.total_ms, "clear_ms": t.clear_ms, "histogram_ms": t.histogram_ms, "scan_ms": t.scan_ms,
+        "scatter_ms": [t.scatter_ms[i] for i in range(t.passes)], "passes": t.passes, "tile_keys": t.tile_keys,
+        "tiles": t.tiles,
+    }
+
+
+# ------------------------------------------------------------------------------ stage entries
+def BuildHistograms(d_keys, r: int, bit_group: int, stream=None):
+    """h[tile][digit] for one digit: ``BuildHistogramsKernel`` (.cu:660-702)."""
+    torch = _torch()
+    _dev_i32(d_keys, "d_keys")
+    n = d_keys.numel()
+    tk = tile_keys(r)
+    tiles = (n + tk - 1) // tk
+    h = torch.empty((tiles, 1 << r), dtype=torch.int32, device=d_keys.device)
+    check(lib().lsdsort_tile_histograms_u32_device(d_keys.data_ptr(), n, r, bit_group, h.data_ptr(), _stream(stream)),
+          "lsdsort_tile_histograms_u32_device")
+    return h
+
+
+def BuildOffsets(d_hist, r: int, stream=None):
+    """(local, global) offset tables from h[tile][digit]: the reference's .cu:862-895."""
+    torch = _torch()
+    _dev_i32(d_hist, "d_hist")
+    tiles = d_hist.shape[0]
+    local = torch.empty_like(d_hist)
+    glob = torch.empty_like(d_hist)
+    scratch = torch.empty(max(int(lib().lsdsort_tile_offsets_scratch_bytes(tiles, r)), 256), dtype=torch.uint8,
+                          device=d_hist.device)
+    check(lib().lsdsort_tile_offsets_u32_device(d_hist.data_ptr(), local.data_ptr(), glob.data_ptr(), tiles, r,
+                                                scratch.data_ptr(), _stream(stream)),
+          "lsdsort_tile_offsets_u32_device")
+    return local, glob
+
+
+def RankScatter(d_in, d_global, r: int, bit_group: int, d_vals=None, stream=None):
+    """One rank-and-scatter pass from a global offset table: ``LSDRadixSortKernel`` (.cu:795-837)."""
+    torch = _torch()
+    _dev_i32(d_in, "d_in")
+    _dev_i32(d_global, "d_global")
+    out = torch.empty_like(d_in)
+    vout = torch.empty_like(d_vals) if d_vals is not None else None
+    check(lib().lsdsort_rank_scatter_u32_device(d_in.data_ptr(), out.data_ptr(),
+                                                d_vals.data_ptr() if d_vals is not None else None,
+                                                vout.data_ptr() if vout is not None else None, d_global.data_ptr(),
+                                                d_in.numel(), r, bit_group, _stream(stream)),
+          "lsdsort_rank_scatter_u32_device")
+    return out if d_vals is None else (out, vout)
+
+
+def DigitHistograms(d_keys, r: int, stream=None):
+    """All 32/r digit histograms in one read (stage 1 of the default pass structure)."""
+    torch = _torch()
+    _dev_i32(d_keys, "d_keys")
+    h = torch.empty((32 // r, 1 << r), dtype=torch.int32, device=d_keys.device)
+    check(lib().lsdsort_digit_histograms_u32_device(d_keys.data_ptr(), d_keys.numel(), r, h.data_ptr(),
+                                                    _stream(stream)), "lsdsort_digit_histograms_u32_device")
+    return h
+
+
+def MSBPartition(d_keys, msb_bits: int, stream=None):
+    """Stable partition by the top ``msb_bits`` bits -> (partitioned keys, int64 bucket counts)."""
+    torch = _torch()
+    _dev_i32(d_keys, "d_keys")
+    n = d_keys.numel()
+    out = torch.empty_like(d_keys)
+    counts = torch.zeros(1 << msb_bits, dtype=torch.int64, device=d_keys.device)
+    ws = torch.empty(max(int(lib().lsdsort_msb_partition_workspace_bytes(n, msb_bits)), 256), dtype=torch.uint8,
+                     device=d_keys.device)
+    check(lib().lsdsort_msb_partition_u32_device(d_keys.data_ptr(), out.data_ptr(), n, msb_bits, counts.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), _stream(stream)),
+          "lsdsort_msb_partition_u32_device")
+    if n:
+        check(lib().lsdsort_check_device(ws.data_ptr(), _stream(stream)), "lsdsort_check_device")
+    return out, counts

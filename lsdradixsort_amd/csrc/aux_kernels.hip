@@ -1,0 +1,391 @@
+// aux_kernels.hip -- stages 1 and 2 (histograms and scans) and the launch dispatchers.
+//
+// Stage 1 stands in for BuildHistogramsKernel (.cu:660-702); stage 2 for the reference's
+// offset construction (.cu:862-895: D2D copy, BlockPrefixSumKernel, two TransposeSMEMKernel
+// launches, GPUPrefixSum + AddBlockSumsKernel).  All of it is small next to stage 3.
+#include "lsd_device.hpp"
+#include "lsd_kernels.hpp"
+
+namespace lsd {
+
+// ------------------------------------------------------------------------------------------
+// Stage 1 (onesweep): every digit histogram of the array in ONE read.
+//
+// A pass permutes keys and never changes them, so the counts LSDRadixSortPass builds at
+// .cu:30-35 for each pass can all be taken from the unsorted input.  Each workgroup keeps
+// G x 2^R counters in LDS (replicated for narrow digits so 64 lanes do not serialise on two
+// or sixteen words), streams keys with 16-byte loads, and flushes once with global atomics.
+// ------------------------------------------------------------------------------------------
+constexpr int kHistThreads = 256;
+constexpr int kHistVecPerThread = 4;   // uint4 loads in flight per thread per iteration
+
+template <int R, int G>
+__global__ void __launch_bounds__(kHistThreads) digit_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                                       uint32_t shift0, uint32_t* __restrict__ hist,
+                                                                       uint32_t vec_chunks)
+{
+    constexpr int H = 1 << R;
+    constexpr int C = hist_copies<R>();
+    __shared__ uint32_t s_hist[G * H * C];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t copy = tid & (C - 1);
+    for (uint32_t j = tid; j < (uint32_t)(G * H * C); j += kHistThreads) s_hist[j] = 0;
+    __syncthreads();
+
+    auto count_key = [&](uint32_t k) {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const uint32_t d = digit_at<R>(k, shift0 + g * R);
+            uint32_t* slot = &s_hist[(g * H + d) * C + copy];
+            if (R >= 6) {
+                // Low-entropy digits (sorted / constant input) would serialise 64 lanes on
+                // one LDS word; when the whole wave agrees, one lane adds 64.
+                const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+                if (__builtin_amdgcn_read_exec() == ~0ull && __all(d == d0)) {
+                    if ((tid & 63u) == 0) atomicAdd(&s_hist[(g * H + d0) * C], 64u);
+                    continue;
+                }
+            }
+            atomicAdd(slot, 1u);
+        }
+    };
+
+    // body: whole uint4 chunks, grid-strided; each chunk is kHistThreads*4 keys
+    const uint4* __restrict__ keys4 = reinterpret_cast<const uint4*>(keys);
+    for (uint32_t c = blockIdx.x * kHistVecPerThread; c < vec_chunks; c += gridDim.x * kHistVecPerThread) {
+        uint4 v[kHistVecPerThread];
+#pragma unroll
+        for (int u = 0; u < kHistVecPerThread; u++) {
+            const uint32_t cc = c + u;
+            v[u] = cc < vec_chunks ? keys4[(size_t)cc * kHistThreads + tid] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < kHistVecPerThread; u++) {
+            if (c + u < vec_chunks) {
+                count_key(v[u].x);
+                count_key(v[u].y);
+                count_key(v[u].z);
+                count_key(v[u].w);
+            }
+        }
+    }
+    // tail: the last (n mod chunk) keys, one per thread per step, by block 0
+    if (blockIdx.x == 0) {
+        const uint32_t tail_begin = vec_chunks * (kHistThreads * 4);
+        for (uint32_t i = tail_begin + tid; i < n; i += kHistThreads) {
+            const uint32_t k = keys[i];
+#pragma unroll
+            for (int g = 0; g < G; g++) atomicAdd(&s_hist[(g * H + digit_at<R>(k, shift0 + g * R)) * C + copy], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < (uint32_t)(G * H); j += kHistThreads) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int c = 0; c < C; c++) sum += s_hist[j * C + c];
+        if (sum) atomicAdd(&hist[j], sum);
+    }
+}
+
+template <int R, int G>
+static hipError_t launch_digit_histograms_inst(uint32_t shift0, const uint32_t* keys, uint32_t n, uint32_t* hist,
+                                               hipStream_t stream)
+{
+    // 16-byte loads need a 16-byte aligned base; otherwise everything goes through the tail.
+    const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
+    const uint32_t vec_chunks = aligned ? n / (kHistThreads * 4) : 0;
+    uint32_t blocks = (vec_chunks + kHistVecPerThread - 1) / kHistVecPerThread;
+    if (blocks > 2048) blocks = 2048;   // 256 CUs x 8: enough waves to cover HBM latency
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL((digit_histograms_kernel<R, G>), dim3(blocks), dim3(kHistThreads), 0, stream, keys, n, shift0,
+                       hist, vec_chunks);
+    return hipGetLastError();
+}
+
+hipError_t launch_digit_histograms(int radix_bits, int groups, uint32_t shift0, const uint32_t* keys, uint32_t n,
+                                   uint32_t* hist, hipStream_t stream)
+{
+    if (groups == 1) {
+        switch (radix_bits) {
+            case 1: return launch_digit_histograms_inst<1, 1>(shift0, keys, n, hist, stream);
+            case 2: return launch_digit_histograms_inst<2, 1>(shift0, keys, n, hist, stream);
+            case 3: return launch_digit_histograms_inst<3, 1>(shift0, keys, n, hist, stream);
+            case 4: return launch_digit_histograms_inst<4, 1>(shift0, keys, n, hist, stream);
+            case 8: return launch_digit_histograms_inst<8, 1>(shift0, keys, n, hist, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (groups * radix_bits != 32) return hipErrorInvalidValue;
+    switch (radix_bits) {
+        case 1: return launch_digit_histograms_inst<1, 32>(shift0, keys, n, hist, stream);
+        case 2: return launch_digit_histograms_inst<2, 16>(shift0, keys, n, hist, stream);
+        case 4: return launch_digit_histograms_inst<4, 8>(shift0, keys, n, hist, stream);
+        case 8: return launch_digit_histograms_inst<8, 4>(shift0, keys, n, hist, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 2 (onesweep): exclusive scan of each group's 2^R digit counts -- the inclusive scan
+// of .cu:38-41 turned exclusive (PrefixSum, .cu:128-139).  One workgroup per group.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) scan_digit_counts_kernel(const uint32_t* __restrict__ hist,
+                                                               uint32_t* __restrict__ base, int bins)
+{
+    __shared__ uint32_t s_wave[4];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t v = tid < (uint32_t)bins ? hist[blockIdx.x * bins + tid] : 0u;
+    uint32_t incl = wave_inclusive_scan(v, lane);
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    for (uint32_t w = 0; w < wave; w++) incl += s_wave[w];
+    if (tid < (uint32_t)bins) base[blockIdx.x * bins + tid] = incl - v;
+}
+
+hipError_t launch_scan_digit_counts(int radix_bits, int groups, const uint32_t* hist, uint32_t* base,
+                                    hipStream_t stream)
+{
+    if (radix_bits < 1 || radix_bits > 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(scan_digit_counts_kernel, dim3(groups), dim3(256), 0, stream, hist, base, 1 << radix_bits);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 1 (staged): per-tile digit counts h[tile][digit], BuildHistogramsKernel .cu:660-702.
+// One workgroup per tile; counters in LDS, one coalesced row written per tile.
+// ------------------------------------------------------------------------------------------
+template <int R, int T>
+__global__ void __launch_bounds__(T) tile_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                           uint32_t shift, uint32_t tile_keys,
+                                                           uint32_t* __restrict__ hist)
+{
+    constexpr int H = 1 << R;
+    constexpr int C = hist_copies<R>();
+    __shared__ uint32_t s_hist[H * C];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t copy = tid & (C - 1);
+    for (uint32_t j = tid; j < (uint32_t)(H * C); j += T) s_hist[j] = 0;
+    __syncthreads();
+    const uint32_t begin = blockIdx.x * tile_keys;
+    const uint32_t end = (n - begin < tile_keys) ? n : begin + tile_keys;
+    for (uint32_t i = begin + tid; i < end; i += T) atomicAdd(&s_hist[digit_at<R>(keys[i], shift) * C + copy], 1u);
+    __syncthreads();
+    for (uint32_t d = tid; d < (uint32_t)H; d += T) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int c = 0; c < C; c++) sum += s_hist[d * C + c];
+        hist[(size_t)blockIdx.x * H + d] = sum;
+    }
+}
+
+hipError_t launch_tile_histograms(int radix_bits, const TileShape& shape, const uint32_t* keys, uint32_t n,
+                                  uint32_t shift, uint32_t* hist, hipStream_t stream)
+{
+    const uint32_t tile_keys = (uint32_t)shape.tile();
+    const uint32_t tiles = (n + tile_keys - 1) / tile_keys;
+    if (tiles == 0) return hipSuccess;
+    switch (radix_bits) {
+#define LSD_CASE(RB)                                                                                              \
+    case RB:                                                                                                      \
+        hipLaunchKernelGGL((tile_histograms_kernel<RB, 256>), dim3(tiles), dim3(256), 0, stream, keys, n, shift, \
+                           tile_keys, hist);                                                                      \
+        break;
+        LSD_CASE(1) LSD_CASE(2) LSD_CASE(3) LSD_CASE(4) LSD_CASE(8)
+#undef LSD_CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 2 (staged): offset tables from h[tile][digit].
+//   local[t][d]  = exclusive scan over d within tile t                       (.cu:869)
+//   global[t][d] = keys with digit < d anywhere + keys with digit d in tiles < t   (.cu:877-895)
+// The reference reaches the second by transposing to digit-major and scanning flat; here the
+// table stays block-major and the digit-major order is walked directly:
+//   (1) column sums over strips of kStrip tiles        -> strip_sum[strip][d]
+//   (2) one workgroup scans strip_sum in digit-major order (d outer, strip inner), exclusive
+//   (3) each (strip, d) thread replays its strip from that base and writes global[t][d].
+// Threads are laid out digit-fastest so every access to a [.][d] row is coalesced.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kStrip = 64;
+
+__global__ void __launch_bounds__(256) local_offsets_kernel(const uint32_t* __restrict__ hist,
+                                                           uint32_t* __restrict__ local, uint32_t tiles, int bins_log2)
+{
+    // 256 / bins rows per workgroup; Hillis-Steele inside each row through LDS
+    __shared__ uint32_t s[2][256];
+    const uint32_t bins = 1u << bins_log2;
+    const uint32_t rows_per_block = 256u >> bins_log2;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t d = tid & (bins - 1);
+    const uint32_t row = blockIdx.x * rows_per_block + (tid >> bins_log2);
+    const bool live = row < tiles;
+    const uint32_t v = live ? hist[(size_t)row * bins + d] : 0u;
+    int cur = 0;
+    s[0][tid] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < bins; off <<= 1) {
+        uint32_t x = s[cur][tid];
+        if (d >= off) x += s[cur][tid - off];
+        s[cur ^ 1][tid] = x;
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (live) local[(size_t)row * bins + d] = s[cur][tid] - v;
+}
+
+__global__ void __launch_bounds__(256) strip_sums_kernel(const uint32_t* __restrict__ hist,
+                                                        uint32_t* __restrict__ strip_sum, uint32_t tiles,
+                                                        uint32_t strips, int bins_log2)
+{
+    const uint32_t bins = 1u << bins_log2;
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;   // (strip, digit), digit fastest
+    const uint32_t strip = gid >> bins_log2, d = gid & (bins - 1);
+    if (strip >= strips) return;
+    const uint32_t t0 = strip * kStrip;
+    const uint32_t t1 = (tiles - t0 < kStrip) ? tiles : t0 + kStrip;
+    uint32_t sum = 0;
+    for (uint32_t t = t0; t < t1; t++) sum += hist[(size_t)t * bins + d];
+    strip_sum[(size_t)strip * bins + d] = sum;
+}
+
+// One workgroup; walks bins*strips entries in digit-major order with a running carry.
+__global__ void __launch_bounds__(1024) scan_strip_sums_kernel(uint32_t* __restrict__ strip_sum, uint32_t strips,
+                                                              int bins_log2)
+{
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t bins = 1u << bins_log2;
+    const uint32_t total = strips << bins_log2;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < total; base += 1024u) {
+        const uint32_t e = base + tid;                 // digit-major linear index
+        const uint32_t d = e / strips, strip = e - d * strips;
+        const bool live = e < total;
+        const uint32_t v = live ? strip_sum[(size_t)strip * bins + d] : 0u;
+        uint32_t incl = wave_inclusive_scan(v, lane);
+        if (lane == 63u) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t carry = s_carry;
+        for (uint32_t w = 0; w < wave; w++) carry += s_wave[w];
+        incl += carry;
+        if (live) strip_sum[(size_t)strip * bins + d] = incl - v;
+        __syncthreads();
+        if (tid == 1023u) s_carry = incl;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) global_offsets_kernel(const uint32_t* __restrict__ hist,
+                                                            const uint32_t* __restrict__ strip_base,
+                                                            uint32_t* __restrict__ global, uint32_t tiles,
+                                                            uint32_t strips, int bins_log2)
+{
+    const uint32_t bins = 1u << bins_log2;
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t strip = gid >> bins_log2, d = gid & (bins - 1);
+    if (strip >= strips) return;
+    const uint32_t t0 = strip * kStrip;
+    const uint32_t t1 = (tiles - t0 < kStrip) ? tiles : t0 + kStrip;
+    uint32_t running = strip_base[(size_t)strip * bins + d];
+    for (uint32_t t = t0; t < t1; t++) {
+        const uint32_t c = hist[(size_t)t * bins + d];
+        global[(size_t)t * bins + d] = running;
+        running += c;
+    }
+}
+
+size_t tile_offsets_scratch_words(size_t tiles, int radix_bits)
+{
+    const size_t strips = (tiles + kStrip - 1) / kStrip;
+    return strips << radix_bits;
+}
+
+hipError_t launch_tile_offsets(int radix_bits, const uint32_t* hist, uint32_t* local, uint32_t* global,
+                               uint32_t tiles, uint32_t* scratch, hipStream_t stream)
+{
+    if (radix_bits < 1 || radix_bits > 8) return hipErrorInvalidValue;
+    if (tiles == 0) return hipSuccess;
+    const uint32_t bins = 1u << radix_bits;
+    if (global) {
+        const uint32_t strips = (tiles + kStrip - 1) / kStrip;
+        const uint32_t threads = strips * bins;
+        const uint32_t blocks = (threads + 255u) / 256u;
+        hipLaunchKernelGGL(strip_sums_kernel, dim3(blocks), dim3(256), 0, stream, hist, scratch, tiles, strips,
+                           radix_bits);
+        hipLaunchKernelGGL(scan_strip_sums_kernel, dim3(1), dim3(1024), 0, stream, scratch, strips, radix_bits);
+        hipLaunchKernelGGL(global_offsets_kernel, dim3(blocks), dim3(256), 0, stream, hist, scratch, global, tiles,
+                           strips, radix_bits);
+    }
+    if (local) {
+        // after `global`: local may alias hist (in-place, like the reference's h[0,GH))
+        const uint32_t rows_per_block = 256u >> radix_bits;
+        const uint32_t blocks = (tiles + rows_per_block - 1) / rows_per_block;
+        hipLaunchKernelGGL(local_offsets_kernel, dim3(blocks), dim3(256), 0, stream, hist, local, tiles, radix_bits);
+    }
+    return hipGetLastError();
+}
+
+__global__ void widen_counts_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, int bins)
+{
+    const int i = threadIdx.x;
+    if (i < bins) out[i] = in[i];
+}
+
+hipError_t launch_widen_counts(const uint32_t* hist32, uint64_t* counts64, int bins, hipStream_t stream)
+{
+    hipLaunchKernelGGL(widen_counts_kernel, dim3(1), dim3(256), 0, stream, hist32, counts64, bins);
+    return hipGetLastError();
+}
+
+__global__ void store_u64_kernel(uint64_t* out, uint64_t value) { *out = value; }
+
+hipError_t launch_store_u64(uint64_t* out, uint64_t value, hipStream_t stream)
+{
+    hipLaunchKernelGGL(store_u64_kernel, dim3(1), dim3(1), 0, stream, out, value);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// rank-and-scatter dispatch: per-radix translation units hold the instantiations.
+// ------------------------------------------------------------------------------------------
+hipError_t launch_rank_scatter_r8(int shape_id, bool chained, const PassParams& p, hipStream_t stream);
+hipError_t launch_rank_scatter_r4(int shape_id, bool chained, const PassParams& p, hipStream_t stream);
+hipError_t launch_rank_scatter_small(int radix_bits, bool chained, const PassParams& p, hipStream_t stream);
+
+static const TileShape kShapesR8[] = {{512, 16}, {256, 16}, {1024, 16}};
+static const TileShape kShapesR4[] = {{512, 16}, {256, 16}};
+static const TileShape kShapesSmall[] = {{256, 16}};
+
+int tile_shapes(int radix_bits, const TileShape** out)
+{
+    switch (radix_bits) {
+        case 8: *out = kShapesR8; return (int)(sizeof(kShapesR8) / sizeof(TileShape));
+        case 4: *out = kShapesR4; return (int)(sizeof(kShapesR4) / sizeof(TileShape));
+        case 1: case 2: case 3: *out = kShapesSmall; return 1;
+        default: *out = nullptr; return 0;
+    }
+}
+
+hipError_t launch_rank_scatter(int radix_bits, const TileShape& shape, bool chained, const PassParams& p,
+                               hipStream_t stream)
+{
+    const TileShape* shapes = nullptr;
+    const int count = tile_shapes(radix_bits, &shapes);
+    int id = -1;
+    for (int i = 0; i < count; i++)
+        if (shapes[i].threads == shape.threads && shapes[i].keys_per_thread == shape.keys_per_thread) id = i;
+    if (id < 0) return hipErrorInvalidValue;
+    if (p.num_tiles == 0) return hipSuccess;
+    switch (radix_bits) {
+        case 8: return launch_rank_scatter_r8(id, chained, p, stream);
+        case 4: return launch_rank_scatter_r4(id, chained, p, stream);
+        default: return launch_rank_scatter_small(radix_bits, chained, p, stream);
+    }
+}
+
+}  // namespace lsd

@@ -1,0 +1,581 @@
+// lsdsort_api.hip -- the C-ABI (include/lsdsort.h) and the host-side pass sequencing.
+//
+// Host counterpart of GPULSDRadixSort (.cu:839-910) and of the alloc/copy/sort/copy body of
+// TestGPULSDRadixSort (.cu:966-1005).  Differences by design: one stream and explicit stream
+// order (the reference leans on legacy default-stream implicit sync between its default
+// stream and two private streams, .cu:841-842); nothing allocated inside the device entry;
+// every HIP error is returned, never fatal; kernel launches are checked (the reference never
+// calls cudaGetLastError).
+#define LSDSORT_BUILD 1
+#include "../../include/lsdsort.h"
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+
+#include "lsd_kernels.hpp"
+
+namespace {
+
+using lsd::PassParams;
+using lsd::TileShape;
+
+thread_local hipError_t g_last_hip = hipSuccess;
+
+#define LSD_HIP(expr)                         \
+    do {                                      \
+        hipError_t e__ = (expr);              \
+        if (e__ != hipSuccess) {              \
+            g_last_hip = e__;                 \
+            (void)hipGetLastError();          \
+            return LSDSORT_ERR_HIP;           \
+        }                                     \
+    } while (0)
+
+constexpr size_t kAlign = 256;
+constexpr size_t kControlBytes = 256;            // u32[64]: [0] fault word, [32..63] tile counters
+constexpr size_t kControlCounterWord = 32;
+constexpr size_t kDigitTableBytes = 4096;        // up to (32/R) x 2^R u32 counters, R <= 8
+
+size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+bool valid_radix(int r) { return r == 1 || r == 2 || r == 4 || r == 8; }
+
+std::atomic<int> g_shape_id[9];   // per radix_bits, 0 = default
+
+const TileShape* current_shape(int radix_bits)
+{
+    const TileShape* shapes = nullptr;
+    const int count = lsd::tile_shapes(radix_bits, &shapes);
+    if (count == 0) return nullptr;
+    int id = g_shape_id[radix_bits].load(std::memory_order_relaxed);
+    if (id < 0 || id >= count) id = 0;
+    return &shapes[id];
+}
+
+// Device workspace carve-up.  Everything before `zero_bytes` is cleared at the start of a sort.
+struct Layout {
+    size_t control = 0;      // fault word + per-pass tile counters
+    size_t digit_hist = 0;   // onesweep: [P][H] counts
+    size_t status = 0;       // onesweep: [tiles][H] tile-status words
+    size_t zero_bytes = 0;
+    size_t digit_base = 0;   // onesweep: [P][H] exclusive scans
+    size_t tile_hist = 0;    // staged: [tiles][H] counts, then local offsets in place
+    size_t tile_global = 0;  // staged: [tiles][H] global offsets
+    size_t scratch = 0;      // staged: strip sums
+    size_t alt_keys = 0;
+    size_t alt_vals = 0;
+    size_t total = 0;
+    uint32_t tiles = 0;
+};
+
+Layout make_layout(size_t n, int radix_bits, bool pairs, int algorithm, const TileShape& shape)
+{
+    Layout L;
+    const size_t bins = (size_t)1 << radix_bits;
+    const size_t tile = (size_t)shape.tile();
+    L.tiles = (uint32_t)((n + tile - 1) / tile);
+    size_t off = 0;
+    L.control = off;
+    off += kControlBytes;
+    if (algorithm == LSDSORT_ALGO_ONESWEEP) {
+        L.digit_hist = off;
+        off += kDigitTableBytes;
+        L.status = off;
+        off = align_up(off + (size_t)L.tiles * bins * sizeof(uint32_t));
+        L.zero_bytes = off;
+        L.digit_base = off;
+        off += kDigitTableBytes;
+    } else {
+        L.zero_bytes = off;
+        L.tile_hist = off;
+        off = align_up(off + (size_t)L.tiles * bins * sizeof(uint32_t));
+        L.tile_global = off;
+        off = align_up(off + (size_t)L.tiles * bins * sizeof(uint32_t));
+        L.scratch = off;
+        off = align_up(off + lsd::tile_offsets_scratch_words(L.tiles, radix_bits) * sizeof(uint32_t));
+    }
+    L.alt_keys = off;
+    off = align_up(off + n * sizeof(uint32_t));
+    if (pairs) {
+        L.alt_vals = off;
+        off = align_up(off + n * sizeof(uint32_t));
+    }
+    L.total = off;
+    return L;
+}
+
+int check_device_ready()
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return LSDSORT_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return LSDSORT_ERR_NO_DEVICE;
+    }
+    static thread_local int checked_dev = -1;
+    if (checked_dev != dev) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            return LSDSORT_ERR_NO_DEVICE;
+        }
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return LSDSORT_ERR_NO_DEVICE;   // code objects are gfx950 only
+        checked_dev = dev;
+    }
+    return LSDSORT_OK;
+}
+
+struct StageEvents {
+    hipEvent_t ev[LSDSORT_MAX_PASSES + 4];
+    int count = 0;
+    bool enabled = false;
+    hipStream_t stream = nullptr;
+    int mark()
+    {
+        if (!enabled) return LSDSORT_OK;
+        LSD_HIP(hipEventCreate(&ev[count]));
+        LSD_HIP(hipEventRecord(ev[count], stream));
+        count++;
+        return LSDSORT_OK;
+    }
+    void destroy()
+    {
+        for (int i = 0; i < count; i++) (void)hipEventDestroy(ev[i]);
+        count = 0;
+    }
+};
+
+#define LSD_TRY(expr)                  \
+    do {                               \
+        int s__ = (expr);              \
+        if (s__ != LSDSORT_OK) return s__; \
+    } while (0)
+
+// The pass loop.  Marks (when timing): 0 start | 1 after clear | 2 after stage 1 | 3 after stage 2 |
+// 4+p after pass p   (staged: stages 1 and 2 are inside the pass; marks 2 and 3 coincide with 1).
+int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, size_t n, int radix_bits,
+             int algorithm, hipStream_t stream, StageEvents* ev, lsdsort_timing* timing)
+{
+    if (!valid_radix(radix_bits)) return LSDSORT_ERR_INVALID_ARG;
+    if (algorithm != LSDSORT_ALGO_ONESWEEP && algorithm != LSDSORT_ALGO_STAGED) return LSDSORT_ERR_INVALID_ARG;
+    if (n > LSDSORT_MAX_KEYS) return LSDSORT_ERR_TOO_LARGE;
+    if (n == 0) return LSDSORT_OK;
+    if (!d_keys) return LSDSORT_ERR_INVALID_ARG;
+    LSD_TRY(check_device_ready());
+    const TileShape* shape = current_shape(radix_bits);
+    if (!shape) return LSDSORT_ERR_INVALID_ARG;
+    const bool pairs = d_vals != nullptr;
+    const Layout L = make_layout(n, radix_bits, pairs, algorithm, *shape);
+    if (!d_ws || (reinterpret_cast<uintptr_t>(d_ws) & (kAlign - 1)) || ws_bytes < L.total) return LSDSORT_ERR_WORKSPACE;
+
+    char* ws = static_cast<char*>(d_ws);
+    uint32_t* control = reinterpret_cast<uint32_t*>(ws + L.control);
+    uint32_t* alt_keys = reinterpret_cast<uint32_t*>(ws + L.alt_keys);
+    uint32_t* alt_vals = pairs ? reinterpret_cast<uint32_t*>(ws + L.alt_vals) : nullptr;
+    const int passes = 32 / radix_bits;
+    const uint32_t bins = 1u << radix_bits;
+    if (timing) {
+        timing->passes = passes;
+        timing->tile_keys = shape->tile();
+        timing->tiles = (int)L.tiles;
+    }
+
+    if (ev) LSD_TRY(ev->mark());
+    LSD_HIP(hipMemsetAsync(ws, 0, L.zero_bytes, stream));
+    if (ev) LSD_TRY(ev->mark());
+
+    uint32_t* digit_hist = nullptr;
+    uint32_t* digit_base = nullptr;
+    if (algorithm == LSDSORT_ALGO_ONESWEEP) {
+        digit_hist = reinterpret_cast<uint32_t*>(ws + L.digit_hist);
+        digit_base = reinterpret_cast<uint32_t*>(ws + L.digit_base);
+        LSD_HIP(lsd::launch_digit_histograms(radix_bits, passes, 0, d_keys, (uint32_t)n, digit_hist, stream));
+        if (ev) LSD_TRY(ev->mark());
+        LSD_HIP(lsd::launch_scan_digit_counts(radix_bits, passes, digit_hist, digit_base, stream));
+        if (ev) LSD_TRY(ev->mark());
+    } else if (ev) {
+        LSD_TRY(ev->mark());
+        LSD_TRY(ev->mark());
+    }
+
+    uint32_t* src = d_keys;
+    uint32_t* dst = alt_keys;
+    uint32_t* vsrc = d_vals;
+    uint32_t* vdst = alt_vals;
+    for (int pass = 0; pass < passes; pass++) {
+        PassParams p{};
+        p.in = src;
+        p.out = dst;
+        p.vals_in = vsrc;
+        p.vals_out = vdst;
+        p.n = (uint32_t)n;
+        p.shift = (uint32_t)(pass * radix_bits);
+        p.num_tiles = L.tiles;
+        p.fault = control;
+        if (algorithm == LSDSORT_ALGO_ONESWEEP) {
+            p.digit_base = digit_base + (size_t)pass * bins;
+            p.status = reinterpret_cast<uint32_t*>(ws + L.status);
+            p.tile_counter = control + kControlCounterWord + pass;
+            p.parity = (uint32_t)(pass & 1);
+            LSD_HIP(lsd::launch_rank_scatter(radix_bits, *shape, true, p, stream));
+        } else {
+            uint32_t* tile_hist = reinterpret_cast<uint32_t*>(ws + L.tile_hist);
+            uint32_t* tile_global = reinterpret_cast<uint32_t*>(ws + L.tile_global);
+            uint32_t* scratch = reinterpret_cast<uint32_t*>(ws + L.scratch);
+            LSD_HIP(lsd::launch_tile_histograms(radix_bits, *shape, src, (uint32_t)n, p.shift, tile_hist, stream));
+            // local offsets are recomputed inside the rank-and-scatter kernel (it needs them for
+            // ranking anyway); only the global table is materialised here.
+            LSD_HIP(lsd::launch_tile_offsets(radix_bits, tile_hist, nullptr, tile_global, L.tiles, scratch, stream));
+            p.global_off = tile_global;
+            LSD_HIP(lsd::launch_rank_scatter(radix_bits, *shape, false, p, stream));
+        }
+        if (ev) LSD_TRY(ev->mark());
+        uint32_t* t = src; src = dst; dst = t;
+        t = vsrc; vsrc = vdst; vdst = t;
+    }
+    // 32 / radix_bits is even for every accepted radix: the result is back in d_keys/d_vals,
+    // as the reference relies on (.cu:905, .cu:1005).
+    return LSDSORT_OK;
+}
+
+int read_fault(void* d_ws, hipStream_t stream)
+{
+    uint32_t fault = 0;
+    LSD_HIP(hipMemcpyAsync(&fault, d_ws, sizeof(fault), hipMemcpyDeviceToHost, stream));
+    LSD_HIP(hipStreamSynchronize(stream));
+    return fault ? LSDSORT_ERR_DEVICE_FAULT : LSDSORT_OK;
+}
+
+int sort_host(uint32_t* keys, uint32_t* vals, size_t n, int radix_bits)
+{
+    if (!valid_radix(radix_bits)) return LSDSORT_ERR_INVALID_ARG;
+    if (n > LSDSORT_MAX_KEYS) return LSDSORT_ERR_TOO_LARGE;
+    if (n == 0) return LSDSORT_OK;
+    if (!keys) return LSDSORT_ERR_INVALID_ARG;
+    LSD_TRY(check_device_ready());
+    const bool pairs = vals != nullptr;
+    const size_t ws_bytes = lsdsort_workspace_bytes_ex(n, radix_bits, pairs ? 1 : 0, LSDSORT_ALGO_ONESWEEP);
+    const size_t bytes = n * sizeof(uint32_t);
+    uint32_t *d_keys = nullptr, *d_vals = nullptr;
+    void* d_ws = nullptr;
+    int status = LSDSORT_OK;
+    auto body = [&]() -> int {
+        LSD_HIP(hipMalloc(&d_keys, bytes));
+        if (pairs) LSD_HIP(hipMalloc(&d_vals, bytes));
+        LSD_HIP(hipMalloc(&d_ws, ws_bytes));
+        LSD_HIP(hipMemcpy(d_keys, keys, bytes, hipMemcpyHostToDevice));                  // .cu:1001
+        if (pairs) LSD_HIP(hipMemcpy(d_vals, vals, bytes, hipMemcpyHostToDevice));
+        LSD_TRY(run_sort(d_keys, d_vals, d_ws, ws_bytes, n, radix_bits, LSDSORT_ALGO_ONESWEEP, nullptr, nullptr,
+                         nullptr));                                                     // .cu:1003
+        LSD_TRY(read_fault(d_ws, nullptr));
+        LSD_HIP(hipMemcpy(keys, d_keys, bytes, hipMemcpyDeviceToHost));                  // .cu:1005
+        if (pairs) LSD_HIP(hipMemcpy(vals, d_vals, bytes, hipMemcpyDeviceToHost));
+        return LSDSORT_OK;
+    };
+    status = body();
+    if (d_ws) (void)hipFree(d_ws);
+    if (d_vals) (void)hipFree(d_vals);
+    if (d_keys) (void)hipFree(d_keys);
+    return status;
+}
+
+struct MsbLayout {
+    size_t control = 0, hist = 256, status = 512, zero_bytes = 0, base = 0, total = 0;
+    uint32_t tiles = 0;
+};
+
+MsbLayout make_msb_layout(size_t n, int msb_bits)
+{
+    MsbLayout L;
+    const TileShape* shape = current_shape(msb_bits ? msb_bits : 1);
+    const size_t tile = (size_t)shape->tile();
+    L.tiles = (uint32_t)((n + tile - 1) / tile);
+    L.zero_bytes = align_up(L.status + (size_t)L.tiles * ((size_t)1 << msb_bits) * sizeof(uint32_t));
+    L.base = L.zero_bytes;
+    L.total = L.base + 256;
+    return L;
+}
+
+}  // namespace
+
+// =============================================================================== C-ABI
+extern "C" {
+
+const char* lsdsort_strerror(int status)
+{
+    switch (status) {
+        case LSDSORT_OK: return "ok";
+        case LSDSORT_ERR_INVALID_ARG: return "invalid argument";
+        case LSDSORT_ERR_NO_DEVICE: return "no usable gfx950 HIP device (there is no CPU path behind this library)";
+        case LSDSORT_ERR_HIP: return "HIP runtime error (see lsdsort_last_hip_error_string)";
+        case LSDSORT_ERR_WORKSPACE: return "workspace null, not 256-byte aligned, or too small";
+        case LSDSORT_ERR_TOO_LARGE: return "n exceeds LSDSORT_MAX_KEYS";
+        case LSDSORT_ERR_UNSUPPORTED: return "unsupported request (multi-GPU runs one process per GPU; see INTEGRATION.md)";
+        case LSDSORT_ERR_DEVICE_FAULT: return "a kernel gave up a bounded wait; output undefined";
+        default: return "unknown lsdsort status";
+    }
+}
+
+int lsdsort_last_hip_error(void) { return (int)g_last_hip; }
+const char* lsdsort_last_hip_error_string(void) { return hipGetErrorString(g_last_hip); }
+
+const char* lsdsort_version(void)
+{
+    static char text[96];
+    static bool init = false;
+    if (!init) {
+        int rt = 0;
+        if (hipRuntimeGetVersion(&rt) != hipSuccess) { (void)hipGetLastError(); rt = 0; }
+        std::snprintf(text, sizeof(text), "lsdsort 0.1.0 gfx950 hip %d", rt);
+        init = true;
+    }
+    return text;
+}
+
+int lsdsort_device_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int usable = 0;
+    for (int d = 0; d < count; d++) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) usable++;
+    }
+    (void)hipGetLastError();
+    return usable;
+}
+
+int lsdsort_set_tile_config(int radix_bits, int config_id)
+{
+    if (radix_bits < 1 || radix_bits > 8) return LSDSORT_ERR_INVALID_ARG;
+    const TileShape* shapes = nullptr;
+    const int count = lsd::tile_shapes(radix_bits, &shapes);
+    if (count == 0) return LSDSORT_ERR_INVALID_ARG;
+    if (config_id < 0) config_id = 0;
+    if (config_id >= count) return LSDSORT_ERR_INVALID_ARG;
+    g_shape_id[radix_bits].store(config_id, std::memory_order_relaxed);
+    return LSDSORT_OK;
+}
+
+size_t lsdsort_tile_keys(int radix_bits)
+{
+    const TileShape* shape = (radix_bits >= 1 && radix_bits <= 8) ? current_shape(radix_bits) : nullptr;
+    return shape ? (size_t)shape->tile() : 0;
+}
+
+size_t lsdsort_workspace_bytes_ex(size_t n, int radix_bits, int pairs, int algorithm)
+{
+    if (!valid_radix(radix_bits) || n > LSDSORT_MAX_KEYS) return 0;
+    if (algorithm != LSDSORT_ALGO_ONESWEEP && algorithm != LSDSORT_ALGO_STAGED) return 0;
+    const TileShape* shape = current_shape(radix_bits);
+    return make_layout(n, radix_bits, pairs != 0, algorithm, *shape).total;
+}
+
+size_t lsdsort_workspace_bytes(size_t n, int radix_bits, int pairs)
+{
+    return lsdsort_workspace_bytes_ex(n, radix_bits, pairs, LSDSORT_ALGO_ONESWEEP);
+}
+
+int lsdsort_u32_device_ex(uint32_t* d_keys, uint32_t* d_vals, void* d_workspace, size_t workspace_bytes, size_t n,
+                          int radix_bits, int algorithm, void* hip_stream)
+{
+    return run_sort(d_keys, d_vals, d_workspace, workspace_bytes, n, radix_bits, algorithm,
+                    static_cast<hipStream_t>(hip_stream), nullptr, nullptr);
+}
+
+int lsdsort_u32_device(uint32_t* d_keys, void* d_workspace, size_t workspace_bytes, size_t n, int radix_bits,
+                       void* hip_stream)
+{
+    return lsdsort_u32_device_ex(d_keys, nullptr, d_workspace, workspace_bytes, n, radix_bits, LSDSORT_ALGO_ONESWEEP,
+                                 hip_stream);
+}
+
+int lsdsort_pairs_u32_device(uint32_t* d_keys, uint32_t* d_vals, void* d_workspace, size_t workspace_bytes, size_t n,
+                             int radix_bits, void* hip_stream)
+{
+    if (n > 0 && !d_vals) return LSDSORT_ERR_INVALID_ARG;
+    return lsdsort_u32_device_ex(d_keys, d_vals, d_workspace, workspace_bytes, n, radix_bits, LSDSORT_ALGO_ONESWEEP,
+                                 hip_stream);
+}
+
+int lsdsort_check_device(void* d_workspace, void* hip_stream)
+{
+    if (!d_workspace) return LSDSORT_ERR_WORKSPACE;
+    LSD_TRY(check_device_ready());
+    return read_fault(d_workspace, static_cast<hipStream_t>(hip_stream));
+}
+
+int lsdsort_u32_device_timed(uint32_t* d_keys, uint32_t* d_vals, void* d_workspace, size_t workspace_bytes, size_t n,
+                             int radix_bits, int algorithm, void* hip_stream, lsdsort_timing* out)
+{
+    if (!out) return LSDSORT_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof(*out));
+    StageEvents ev;
+    ev.enabled = true;
+    ev.stream = static_cast<hipStream_t>(hip_stream);
+    int status = run_sort(d_keys, d_vals, d_workspace, workspace_bytes, n, radix_bits, algorithm, ev.stream, &ev, out);
+    if (status == LSDSORT_OK && ev.count >= 4) {
+        auto finish = [&]() -> int {
+            LSD_HIP(hipEventSynchronize(ev.ev[ev.count - 1]));
+            LSD_HIP(hipEventElapsedTime(&out->total_ms, ev.ev[0], ev.ev[ev.count - 1]));
+            LSD_HIP(hipEventElapsedTime(&out->clear_ms, ev.ev[0], ev.ev[1]));
+            LSD_HIP(hipEventElapsedTime(&out->histogram_ms, ev.ev[1], ev.ev[2]));
+            LSD_HIP(hipEventElapsedTime(&out->scan_ms, ev.ev[2], ev.ev[3]));
+            for (int p = 0; p + 4 < ev.count && p < LSDSORT_MAX_PASSES; p++)
+                LSD_HIP(hipEventElapsedTime(&out->scatter_ms[p], ev.ev[3 + p], ev.ev[4 + p]));
+            return LSDSORT_OK;
+        };
+        status = finish();
+    }
+    ev.destroy();
+    return status;
+}
+
+int lsdsort_u32_ex(uint32_t* keys, size_t n, int radix_bits, int num_gpus)
+{
+    if (num_gpus == 0) return LSDSORT_ERR_NO_DEVICE;     // the CPU path is the oracle, not the product
+    if (num_gpus < 0) return LSDSORT_ERR_INVALID_ARG;
+    if (num_gpus > 1) return LSDSORT_ERR_UNSUPPORTED;    // one process per GPU: lsdsort_msb_partition_u32_device + RCCL
+    return sort_host(keys, nullptr, n, radix_bits);
+}
+
+int lsdsort_u32(uint32_t* keys, size_t n) { return lsdsort_u32_ex(keys, n, 8, 1); }
+
+int lsdsort_pairs_u32(uint32_t* keys, uint32_t* vals, size_t n)
+{
+    if (n > 0 && !vals) return LSDSORT_ERR_INVALID_ARG;
+    return sort_host(keys, vals, n, 8);
+}
+
+// ---- stage entries ---------------------------------------------------------------------------
+int lsdsort_tile_histograms_u32_device(const uint32_t* d_keys, size_t n, int radix_bits, int bit_group,
+                                       uint32_t* d_hist, void* hip_stream)
+{
+    if (!valid_radix(radix_bits) || bit_group < 0 || (bit_group + 1) * radix_bits > 32) return LSDSORT_ERR_INVALID_ARG;
+    if (n > LSDSORT_MAX_KEYS) return LSDSORT_ERR_TOO_LARGE;
+    if (n == 0) return LSDSORT_OK;
+    if (!d_keys || !d_hist) return LSDSORT_ERR_INVALID_ARG;
+    LSD_TRY(check_device_ready());
+    LSD_HIP(lsd::launch_tile_histograms(radix_bits, *current_shape(radix_bits), d_keys, (uint32_t)n,
+                                        (uint32_t)(bit_group * radix_bits), d_hist, static_cast<hipStream_t>(hip_stream)));
+    return LSDSORT_OK;
+}
+
+size_t lsdsort_tile_offsets_scratch_bytes(size_t tiles, int radix_bits)
+{
+    if (!valid_radix(radix_bits)) return 0;
+    return align_up(lsd::tile_offsets_scratch_words(tiles, radix_bits) * sizeof(uint32_t));
+}
+
+int lsdsort_tile_offsets_u32_device(const uint32_t* d_hist, uint32_t* d_local, uint32_t* d_global, size_t tiles,
+                                    int radix_bits, void* d_scratch, void* hip_stream)
+{
+    if (!valid_radix(radix_bits)) return LSDSORT_ERR_INVALID_ARG;
+    if (tiles == 0) return LSDSORT_OK;
+    if (tiles > 0xffffffffu || !d_hist || (d_global && !d_scratch)) return LSDSORT_ERR_INVALID_ARG;
+    LSD_TRY(check_device_ready());
+    LSD_HIP(lsd::launch_tile_offsets(radix_bits, d_hist, d_local, d_global, (uint32_t)tiles,
+                                     static_cast<uint32_t*>(d_scratch), static_cast<hipStream_t>(hip_stream)));
+    return LSDSORT_OK;
+}
+
+int lsdsort_rank_scatter_u32_device(const uint32_t* d_in, uint32_t* d_out, const uint32_t* d_vals_in,
+                                    uint32_t* d_vals_out, const uint32_t* d_global, size_t n, int radix_bits,
+                                    int bit_group, void* hip_stream)
+{
+    if (!valid_radix(radix_bits) || bit_group < 0 || (bit_group + 1) * radix_bits > 32) return LSDSORT_ERR_INVALID_ARG;
+    if (n > LSDSORT_MAX_KEYS) return LSDSORT_ERR_TOO_LARGE;
+    if (n == 0) return LSDSORT_OK;
+    if (!d_in || !d_out || !d_global || ((d_vals_in == nullptr) != (d_vals_out == nullptr))) return LSDSORT_ERR_INVALID_ARG;
+    LSD_TRY(check_device_ready());
+    const TileShape* shape = current_shape(radix_bits);
+    PassParams p{};
+    p.in = d_in;
+    p.out = d_out;
+    p.vals_in = d_vals_in;
+    p.vals_out = d_vals_out;
+    p.n = (uint32_t)n;
+    p.shift = (uint32_t)(bit_group * radix_bits);
+    p.num_tiles = (uint32_t)((n + shape->tile() - 1) / shape->tile());
+    p.global_off = d_global;
+    LSD_HIP(lsd::launch_rank_scatter(radix_bits, *shape, false, p, static_cast<hipStream_t>(hip_stream)));
+    return LSDSORT_OK;
+}
+
+int lsdsort_digit_histograms_u32_device(const uint32_t* d_keys, size_t n, int radix_bits, uint32_t* d_hist,
+                                        void* hip_stream)
+{
+    if (!valid_radix(radix_bits)) return LSDSORT_ERR_INVALID_ARG;
+    if (n > LSDSORT_MAX_KEYS) return LSDSORT_ERR_TOO_LARGE;
+    if (!d_hist || (n > 0 && !d_keys)) return LSDSORT_ERR_INVALID_ARG;
+    LSD_TRY(check_device_ready());
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const int groups = 32 / radix_bits;
+    LSD_HIP(hipMemsetAsync(d_hist, 0, (size_t)groups * ((size_t)1 << radix_bits) * sizeof(uint32_t), stream));
+    if (n == 0) return LSDSORT_OK;
+    LSD_HIP(lsd::launch_digit_histograms(radix_bits, groups, 0, d_keys, (uint32_t)n, d_hist, stream));
+    return LSDSORT_OK;
+}
+
+// ---- multi-GPU building block ----------------------------------------------------------------
+size_t lsdsort_msb_partition_workspace_bytes(size_t n, int msb_bits)
+{
+    if (msb_bits < 0 || msb_bits > 3 || n > LSDSORT_MAX_KEYS) return 0;
+    return make_msb_layout(n, msb_bits).total;
+}
+
+int lsdsort_msb_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size_t n, int msb_bits,
+                                     uint64_t* d_counts, void* d_workspace, size_t workspace_bytes, void* hip_stream)
+{
+    if (msb_bits < 0 || msb_bits > 3 || !d_counts) return LSDSORT_ERR_INVALID_ARG;
+    if (n > LSDSORT_MAX_KEYS) return LSDSORT_ERR_TOO_LARGE;
+    if (n > 0 && (!d_in || !d_out || d_in == d_out)) return LSDSORT_ERR_INVALID_ARG;
+    LSD_TRY(check_device_ready());
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const MsbLayout L = make_msb_layout(n, msb_bits);
+    if (!d_workspace || (reinterpret_cast<uintptr_t>(d_workspace) & (kAlign - 1)) || workspace_bytes < L.total)
+        return LSDSORT_ERR_WORKSPACE;
+    char* ws = static_cast<char*>(d_workspace);
+    uint32_t* control = reinterpret_cast<uint32_t*>(ws + L.control);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(ws + L.hist);
+    uint32_t* base = reinterpret_cast<uint32_t*>(ws + L.base);
+    const int bins = 1 << msb_bits;
+    LSD_HIP(hipMemsetAsync(ws, 0, L.zero_bytes, stream));
+    if (msb_bits == 0) {
+        // one bucket: the shard itself
+        if (n) LSD_HIP(hipMemcpyAsync(d_out, d_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        LSD_HIP(lsd::launch_store_u64(d_counts, (uint64_t)n, stream));
+        return LSDSORT_OK;
+    }
+    if (n) {
+        const uint32_t shift = (uint32_t)(32 - msb_bits);
+        LSD_HIP(lsd::launch_digit_histograms(msb_bits, 1, shift, d_in, (uint32_t)n, hist, stream));
+        LSD_HIP(lsd::launch_scan_digit_counts(msb_bits, 1, hist, base, stream));
+        PassParams p{};
+        p.in = d_in;
+        p.out = d_out;
+        p.n = (uint32_t)n;
+        p.shift = shift;
+        p.num_tiles = L.tiles;
+        p.digit_base = base;
+        p.status = reinterpret_cast<uint32_t*>(ws + L.status);
+        p.tile_counter = control + kControlCounterWord;
+        p.parity = 0;
+        p.fault = control;
+        LSD_HIP(lsd::launch_rank_scatter(msb_bits, *current_shape(msb_bits), true, p, stream));
+    }
+    LSD_HIP(lsd::launch_widen_counts(hist, d_counts, bins, stream));
+    return LSDSORT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,16 @@
+// rank_scatter_r4.hip -- 4-bit-digit instantiations of the rank-and-scatter kernel
+// (BASELINE.json configs[1]).  Shape ids index kShapesR4 in aux_kernels.hip.
+#include "rank_scatter.hpp"
+
+namespace lsd {
+
+hipError_t launch_rank_scatter_r4(int shape_id, bool chained, const PassParams& p, hipStream_t stream)
+{
+    switch (shape_id) {
+        case 0: return launch_rank_scatter_shape<4, 512, 16>(chained, p, stream);
+        case 1: return launch_rank_scatter_shape<4, 256, 16>(chained, p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace lsd

@@ -1,0 +1,17 @@
+// rank_scatter_r8.hip -- 8-bit-digit instantiations of the rank-and-scatter kernel
+// (BASELINE.json configs[2] and configs[4]).  Shape ids index kShapesR8 in aux_kernels.hip.
+#include "rank_scatter.hpp"
+
+namespace lsd {
+
+hipError_t launch_rank_scatter_r8(int shape_id, bool chained, const PassParams& p, hipStream_t stream)
+{
+    switch (shape_id) {
+        case 0: return launch_rank_scatter_shape<8, 512, 16>(chained, p, stream);
+        case 1: return launch_rank_scatter_shape<8, 256, 16>(chained, p, stream);
+        case 2: return launch_rank_scatter_shape<8, 1024, 16>(chained, p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace lsd
