@@ -1,0 +1,314 @@
+"""GPU suite: the HIP path, through the C-ABI, against the oracle and the golden vectors.
+
+Shaped like the reference's own self-checks: whole-sort output vs the CPU LSD result
+(TestGPULSDRadixSort, LSDRadixSort.cu:1018), histograms vs BuildHistogramsCPU (.cu:785), scans
+vs PrefixSum (.cu:364) -- plus everything the reference never tries (section 4 of SURVEY.md):
+ragged sizes, duplicates, constant, sorted and reversed inputs, key/value pairs.
+Bit-exact everywhere: integer work, tolerance zero.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ALGOS = {"onesweep": 0, "staged": 1}
+
+
+def _sort_dev(lsd, keys, r, algo=0, vals=None):
+    d = lsd.to_device(keys)
+    dv = lsd.to_device(vals) if vals is not None else None
+    lsd.GPULSDRadixSort(d, r, d_vals=dv, algorithm=algo, check_fault=True)
+    if vals is None:
+        return lsd.to_host(d)
+    return lsd.to_host(d), lsd.to_host(dv)
+
+
+# ----------------------------------------------------------------------------- golden vectors
+@pytest.mark.parametrize("algo", list(ALGOS))
+@pytest.mark.parametrize("r", [1, 2, 4, 8])
+def test_golden_cases(gpu, golden, oracle_mod, algo, r):
+    for name in golden["case_names"]:
+        keys, expect = golden[f"in__{name}"], golden[f"sorted__{name}"]
+        got = _sort_dev(gpu, keys, r, ALGOS[algo])
+        bad = oracle_mod.first_mismatch(got, expect)
+        assert bad == expect.size, f"{name} r={r} {algo}: first mismatch at {bad}"
+
+
+def test_golden_pairs(gpu, golden):
+    for r in (4, 8):
+        for algo in ALGOS.values():
+            k, v = _sort_dev(gpu, golden["pairs_keys"], r, algo, golden["pairs_vals"])
+            assert np.array_equal(k, golden["pairs_sorted_keys"]), (r, algo)
+            assert np.array_equal(v, golden["pairs_sorted_vals"]), (r, algo)
+
+
+@pytest.mark.parametrize("r", [4, 8])
+def test_pass_states_match_reference_passes(gpu, golden, r):
+    """After pass g the array equals what the reference's LSDRadixSortPass leaves (.cu:25-54):
+    the stage entries chained by hand, one pass at a time."""
+    cur = gpu.to_device(golden["passes_in"])
+    states = golden[f"passes_r{r}"]
+    for g in range(32 // r):
+        h = gpu.BuildHistograms(cur, r, g)
+        _, glob = gpu.BuildOffsets(h, r)
+        cur = gpu.RankScatter(cur, glob, r, g)
+        assert np.array_equal(gpu.to_host(cur), states[g]), (r, g)
+
+
+# ----------------------------------------------------------------------------- host-pointer entries
+def test_host_pointer_sort(gpu, golden, oracle_mod):
+    for name in ("uniform_16384_seed0", "uniform_12345_seed1", "n1", "n2", "allmax_4099"):
+        keys = golden[f"in__{name}"].copy()
+        assert gpu.sort(keys) is keys
+        assert np.array_equal(keys, golden[f"sorted__{name}"]), name
+    keys = oracle_mod.mt19937_keys((1 << 20) + 3, 21)       # BASELINE configs[0] size, through the GPU
+    expect = oracle_mod.std_sort(keys)
+    assert np.array_equal(gpu.sort(keys.copy(), radix_bits=4), expect)
+    empty = np.zeros(0, dtype=np.uint32)
+    assert gpu.sort(empty).size == 0
+
+
+def test_host_pointer_pairs(gpu, golden):
+    k, v = golden["pairs_keys"].copy(), golden["pairs_vals"].copy()
+    gpu.sort_pairs(k, v)
+    assert np.array_equal(k, golden["pairs_sorted_keys"]) and np.array_equal(v, golden["pairs_sorted_vals"])
+
+
+# ----------------------------------------------------------------------------- against the oracle, seeded
+@pytest.mark.parametrize("algo", list(ALGOS))
+@pytest.mark.parametrize("r", [4, 8])
+@pytest.mark.parametrize("n,seed", [(8192, 1), (8193, 2), (3 * 8192 - 1, 3), ((1 << 20) + 17, 0), ((1 << 22) + 4099, 5)])
+def test_uniform_vs_oracle(gpu, oracle_mod, algo, r, n, seed):
+    keys = oracle_mod.mt19937_keys(n, seed)
+    got = _sort_dev(gpu, keys, r, ALGOS[algo])
+    expect = oracle_mod.lsd_sort(keys, r)        # == std::sort, as the reference asserts (.cu:120)
+    bad = oracle_mod.first_mismatch(got, expect)
+    assert bad == n, f"first mismatch at {bad}: got {got[bad]} expect {expect[bad]}"
+
+
+@pytest.mark.parametrize("r", [1, 2])
+def test_narrow_radix_vs_oracle(gpu, oracle_mod, r):
+    keys = oracle_mod.mt19937_keys((1 << 18) + 77, 12)
+    for algo in ALGOS.values():
+        assert np.array_equal(_sort_dev(gpu, keys, r, algo), oracle_mod.std_sort(keys))
+
+
+@pytest.mark.parametrize("r", [4, 8])
+def test_distributions(gpu, oracle_mod, r):
+    n = (1 << 21) + 1234
+    base = oracle_mod.mt19937_keys(n, 33)
+    cases = {
+        "allequal": np.full(n, 0x12345678, dtype=np.uint32),
+        "allzero": np.zeros(n, dtype=np.uint32),
+        "allmax": np.full(n, 0xFFFFFFFF, dtype=np.uint32),          # indistinguishable from tail padding
+        "sorted": np.sort(base),
+        "reverse": np.sort(base)[::-1].copy(),
+        "dup3": (base % 3).astype(np.uint32) * np.uint32(0x55555555),
+        "low8": (base & 0xFF).astype(np.uint32),
+        "high8": (base & 0xFF000000).astype(np.uint32),
+        "mid": (base & 0x00FFFF00).astype(np.uint32),
+        "two_values_far": np.where(base & 1, np.uint32(0xFFFFFFFF), np.uint32(0)).astype(np.uint32),
+    }
+    for name, keys in cases.items():
+        got = _sort_dev(gpu, keys, r)
+        assert np.array_equal(got, np.sort(keys)), (name, r)
+
+
+@pytest.mark.parametrize("r", [4, 8])
+def test_pairs_vs_stable_sort(gpu, oracle_mod, r):
+    n = (1 << 20) + 9
+    keys = (oracle_mod.mt19937_keys(n, 41) % 1021).astype(np.uint32) * np.uint32(0x00400801)   # heavy duplicates
+    vals = np.arange(n, dtype=np.uint32)
+    ek, ev = oracle_mod.std_stable_sort_pairs(keys, vals)
+    for algo in ALGOS.values():
+        k, v = _sort_dev(gpu, keys, r, algo, vals)
+        assert np.array_equal(k, ek), (r, algo)
+        assert np.array_equal(v, ev), (r, algo, "payload order among equal keys = stability")
+    # all keys equal: the payload must come back untouched
+    k, v = _sort_dev(gpu, np.full(n, 7, dtype=np.uint32), r, 0, vals)
+    assert np.array_equal(v, vals)
+
+
+def test_tile_configs(gpu, oracle_mod):
+    keys = oracle_mod.mt19937_keys((1 << 20) + 5, 8)
+    expect = np.sort(keys)
+    vals = np.arange(keys.size, dtype=np.uint32)
+    ek, ev = oracle_mod.std_stable_sort_pairs(keys, vals)
+    try:
+        for r, count in ((8, 3), (4, 2)):
+            for cfg in range(count):
+                gpu.set_tile_config(r, cfg)
+                for algo in ALGOS.values():
+                    assert np.array_equal(_sort_dev(gpu, keys, r, algo), expect), (r, cfg, algo)
+                k, v = _sort_dev(gpu, keys, r, 0, vals)
+                assert np.array_equal(k, ek) and np.array_equal(v, ev), (r, cfg)
+    finally:
+        gpu.set_tile_config(8, -1)
+        gpu.set_tile_config(4, -1)
+
+
+def test_workspace_reuse_and_idempotence(gpu, oracle_mod):
+    """One workspace across sorts of different data (the tile-status words are recycled), and
+    sorting a sorted array changes nothing."""
+    import torch
+
+    n = (1 << 20) + 1
+    ws = gpu.alloc_workspace(n, 8)
+    ws.fill_(0xA5)                                     # garbage workspace must not matter
+    for seed in (1, 2, 3):
+        keys = oracle_mod.mt19937_keys(n, seed)
+        d = gpu.to_device(keys)
+        gpu.GPULSDRadixSort(d, 8, workspace=ws, check_fault=True)
+        assert np.array_equal(gpu.to_host(d), np.sort(keys)), seed
+        before = d.clone()
+        gpu.GPULSDRadixSort(d, 8, workspace=ws, check_fault=True)
+        assert torch.equal(d, before)
+
+
+def test_device_entry_errors(gpu):
+    import torch
+
+    from lsdradixsort_amd import errors
+
+    L = gpu.lib()
+    d = gpu.to_device(np.arange(5000, dtype=np.uint32))
+    ws = gpu.alloc_workspace(5000, 8)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert L.lsdsort_u32_device(d.data_ptr(), ws.data_ptr(), 16, 5000, 8, stream) == errors.LSDSORT_ERR_WORKSPACE
+    assert L.lsdsort_u32_device(d.data_ptr(), ws.data_ptr() + 4, ws.numel() - 4, 5000, 8, stream) == errors.LSDSORT_ERR_WORKSPACE
+    assert L.lsdsort_u32_device(d.data_ptr(), None, 0, 5000, 8, stream) == errors.LSDSORT_ERR_WORKSPACE
+    assert L.lsdsort_u32_device(None, ws.data_ptr(), ws.numel(), 5000, 8, stream) == errors.LSDSORT_ERR_INVALID_ARG
+    assert L.lsdsort_u32_device(d.data_ptr(), ws.data_ptr(), ws.numel(), 5000, 3, stream) == errors.LSDSORT_ERR_INVALID_ARG
+    assert L.lsdsort_u32_device(None, None, 0, 0, 8, stream) == errors.LSDSORT_OK
+    torch.cuda.synchronize()
+    assert np.array_equal(gpu.to_host(d), np.arange(5000, dtype=np.uint32))
+
+
+# ----------------------------------------------------------------------------- stage-level parity
+@pytest.mark.parametrize("r,bg", [(8, 0), (8, 3), (4, 5), (2, 9), (1, 18)])
+def test_stage_histograms(gpu, oracle_mod, r, bg):
+    """a2: h[tile][digit] vs the restated BuildHistogramsCPU (.cu:643-658)."""
+    keys = oracle_mod.mt19937_keys(5 * gpu.tile_keys(r) + 321, 50 + r)
+    h = gpu.to_host(gpu.BuildHistograms(gpu.to_device(keys), r, bg).reshape(-1)).reshape(-1, 1 << r)
+    assert np.array_equal(h, oracle_mod.tile_histograms(keys, gpu.tile_keys(r), r, bg))
+
+
+def test_stage_histograms_reference_vector(gpu, golden):
+    """The reference's own BuildHistogramsCPU output, regrouped to our tile size."""
+    keys = golden["hist_in"]                                   # 8192 keys = 8 reference blocks of 1024
+    assert gpu.tile_keys(8) % 1024 == 0
+    per_ref_tile = gpu.tile_keys(8) // 1024
+    ref = golden["hist_block1024_r8_bg1"].astype(np.uint64)
+    ref = ref.reshape(-1, per_ref_tile, 256).sum(axis=1)
+    h = gpu.to_host(gpu.BuildHistograms(gpu.to_device(keys), 8, 1).reshape(-1)).reshape(-1, 256)
+    assert np.array_equal(h.astype(np.uint64), ref)
+
+
+@pytest.mark.parametrize("r,tiles", [(8, 1), (8, 63), (8, 64), (8, 1000), (4, 129), (2, 4097), (1, 70000)])
+def test_stage_offsets(gpu, oracle_mod, r, tiles):
+    """a3-a6: local (per-tile exclusive scan, .cu:869) and global (digit-major exclusive scan,
+    .cu:877-895) tables vs the restatement; counts are arbitrary, not tied to a key array."""
+    rng = np.random.default_rng(r * 1000 + tiles)
+    hist = rng.integers(0, 9000, size=(tiles, 1 << r), dtype=np.uint32)
+    d_local, d_global = gpu.BuildOffsets(gpu.to_device(hist.reshape(-1)).reshape(tiles, 1 << r), r)
+    assert np.array_equal(gpu.to_host(d_local.reshape(-1)).reshape(hist.shape), oracle_mod.local_offsets(hist, r))
+    assert np.array_equal(gpu.to_host(d_global.reshape(-1)).reshape(hist.shape), oracle_mod.global_offsets(hist, r))
+
+
+def test_stage_scan_reference_vector(gpu, golden):
+    """PrefixSum known answer {3,1,4,1,5} -> {0,3,4,8,9} (.cu:128-139) through the offset stage:
+    one tile of 2^3... the scan entry works on 2^r columns, so pad to r=8 with zeros."""
+    row = np.zeros((1, 256), dtype=np.uint32)
+    row[0, :5] = golden["scan_kat_in"]
+    d_local, _ = gpu.BuildOffsets(gpu.to_device(row.reshape(-1)).reshape(1, 256), 8)
+    assert list(gpu.to_host(d_local.reshape(-1))[:5]) == list(golden["scan_kat_out"])
+
+
+@pytest.mark.parametrize("r,bg", [(8, 1), (4, 2), (2, 0), (1, 31)])
+def test_stage_rank_scatter(gpu, oracle_mod, r, bg):
+    """a7: dst = rank - local[d] + global[d] (.cu:833) vs the restatement, and vs one CPU pass."""
+    tile = gpu.tile_keys(r)
+    keys = oracle_mod.mt19937_keys(7 * tile + 11, 60 + r)
+    h = oracle_mod.tile_histograms(keys, tile, r, bg)
+    local, glob = oracle_mod.local_offsets(h, r), oracle_mod.global_offsets(h, r)
+    expect = oracle_mod.rank_scatter(keys, local, glob, tile, r, bg)
+    assert np.array_equal(expect, oracle_mod.lsd_pass(keys, r, bg))
+    d_glob = gpu.to_device(glob.reshape(-1)).reshape(glob.shape)
+    got = gpu.to_host(gpu.RankScatter(gpu.to_device(keys), d_glob, r, bg))
+    assert np.array_equal(got, expect)
+
+
+@pytest.mark.parametrize("r", [1, 2, 4, 8])
+def test_stage_digit_histograms(gpu, oracle_mod, r):
+    for n, seed in ((1, 1), (1023, 2), ((1 << 20) + 13, 3)):
+        keys = oracle_mod.mt19937_keys(n, seed)
+        got = gpu.to_host(gpu.DigitHistograms(gpu.to_device(keys), r).reshape(-1)).reshape(32 // r, 1 << r)
+        assert np.array_equal(got.astype(np.uint64), oracle_mod.digit_histograms(keys, r)), (r, n)
+    const = np.full(300001, 0xA5A5A5A5, dtype=np.uint32)      # wave-uniform digits take the aggregated path
+    got = gpu.to_host(gpu.DigitHistograms(gpu.to_device(const), r).reshape(-1)).reshape(32 // r, 1 << r)
+    assert np.array_equal(got.astype(np.uint64), oracle_mod.digit_histograms(const, r))
+
+
+@pytest.mark.parametrize("msb_bits", [0, 1, 2, 3])
+def test_msb_partition(gpu, oracle_mod, msb_bits):
+    for n, seed in ((1, 1), (4097, 2), ((1 << 20) + 7, 3)):
+        keys = oracle_mod.mt19937_keys(n, seed)
+        out, counts = gpu.MSBPartition(gpu.to_device(keys), msb_bits)
+        eo, ec = oracle_mod.msb_partition(keys, msb_bits)
+        assert np.array_equal(counts.cpu().numpy().astype(np.uint64), ec), (msb_bits, n)
+        assert np.array_equal(gpu.to_host(out), eo), (msb_bits, n)
+
+
+# ----------------------------------------------------------------------------- full size, by property
+def _as_u64(t):
+    import torch
+
+    return t.to(torch.int64) & 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("r", [8, 4])
+def test_full_size_properties(gpu, oracle_mod, r):
+    """BASELINE configs[1]/[2]: 2^28 keys.  Too big for the CPU oracle in test time, so:
+    sortedness, permutation (all digit histograms unchanged + checksums), idempotence, and a
+    test-only cross-check against torch.sort (rocPRIM) of the same array."""
+    import torch
+
+    n = 1 << 28
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + r)
+    d = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda", generator=gen)
+    hist_before = gpu.DigitHistograms(d, 8).clone()
+    sum_before = int(_as_u64(d).sum().item())
+    xor_before = int(torch.bitwise_xor(d[: n // 2], d[n // 2:]).sum().item())
+    expect = torch.sort(_as_u64(d)).values
+    gpu.GPULSDRadixSort(d, r, check_fault=True)
+    u = _as_u64(d)
+    assert bool((u[1:] >= u[:-1]).all()), "not sorted"
+    assert torch.equal(gpu.DigitHistograms(d, 8), hist_before), "not a permutation of the input"
+    assert int(u.sum().item()) == sum_before
+    assert torch.equal(u, expect), "differs from torch.sort of the same keys"
+    del expect, u
+    again = d.clone()
+    gpu.GPULSDRadixSort(again, r, check_fault=True)
+    assert torch.equal(again, d), "sorting the sorted array changed it"
+    _ = xor_before
+
+
+def test_full_size_pairs_properties(gpu):
+    """BASELINE configs[4]: 2^27 (key, payload) pairs = 1 GiB.  Payload = original index, so
+    stability is checkable: among equal keys payloads ascend, and keys[payload] == sorted keys."""
+    import torch
+
+    n = 1 << 27
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(99)
+    keys = torch.randint(0, 1 << 20, (n,), dtype=torch.int32, device="cuda", generator=gen) * 2048 + 5   # ~128 copies of each key
+    orig = keys.clone()
+    vals = torch.arange(n, dtype=torch.int32, device="cuda")
+    gpu.GPULSDRadixSort(keys, 8, d_vals=vals, check_fault=True)
+    k, v = _as_u64(keys), vals.to(torch.int64)
+    assert bool((k[1:] >= k[:-1]).all())
+    assert torch.equal(orig[v], keys), "payload does not point at its key"
+    same = k[1:] == k[:-1]
+    assert bool((v[1:][same] > v[:-1][same]).all()), "equal keys out of input order: not stable"
+    assert int(v.sum().item()) == n * (n - 1) // 2
