@@ -1,0 +1,105 @@
+"""One-process-per-GPU sort across the GPUs of a node (BASELINE.json configs[3]).
+
+New work: the reference is single-GPU.  Keys are range-partitioned by
+their most significant bits -- rank b ends up owning every key whose top log2(world) bits
+equal b -- with exactly ONE exchange step:
+
+  1. local stable partition by the top bits          lsdsort_msb_partition_u32_device (HIP)
+  2. all-gather of the world x world bucket counts   torch.distributed (RCCL over xGMI)
+  3. variable all-to-all of the buckets              all_to_all_single (grouped send/recv: every
+                                                     rank streams to its 7 peers at once, so all
+                                                     xGMI links are busy; no ring)
+  4. local LSD sort of what arrived                  lsdsort_u32_device (HIP)
+
+The globally sorted array is the concatenation of the ranks' results in rank order.  All
+compute is in liblsdsort.so; ``torch.distributed`` is only the transport.  The compute calls
+go through a small backend object so the exchange logic can be exercised on CPU tensors with
+``gloo`` in tests (tests inject an oracle-backed backend; the product default is HIP and there
+is no other in this package).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+def _log2_exact(world: int) -> int:
+    bits = world.bit_length() - 1
+    if world < 1 or (1 << bits) != world or bits > 3:
+        raise ValueError(f"world size must be 1, 2, 4 or 8 (MSB buckets), got {world}")
+    return bits
+
+
+class HipBackend:
+    """The product's compute backend: liblsdsort.so on the current CUDA/HIP device."""
+
+    def __init__(self, radix_bits: int = 8):
+        from . import api
+
+        self._api = api
+        self.radix_bits = radix_bits
+        self._ws = None
+
+    def msb_partition(self, keys, msb_bits: int):
+        return self._api.MSBPartition(keys, msb_bits)
+
+    def sort_inplace(self, keys):
+        n = keys.numel()
+        need = self._api.workspace_bytes(n, self.radix_bits)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = self._api.alloc_workspace(n, self.radix_bits, device=keys.device)
+        self._api.GPULSDRadixSort(keys, self.radix_bits, workspace=self._ws)
+        return keys
+
+    def empty_like(self, ref, n: int):
+        import torch
+
+        return torch.empty(n, dtype=ref.dtype, device=ref.device)
+
+
+@dataclass
+class ShardResult:
+    keys: object            # this rank's slice of the globally sorted array (torch tensor)
+    global_offset: int      # index of keys[0] in the global order
+    counts: object          # world x world int64 matrix: counts[src][dst] = keys src sent to dst
+
+
+def distributed_sort(local_keys, backend=None, group=None) -> ShardResult:
+    """Sort the union of every rank's ``local_keys``; returns this rank's slice.
+
+    ``local_keys``: int32 tensor of uint32 bit patterns on this rank's device.  Collective:
+    every rank of ``group`` must call it.  Result slices concatenate in rank order.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if backend is None:
+        backend = HipBackend()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    msb_bits = _log2_exact(world)
+
+    if world == 1:
+        out = local_keys.clone()
+        backend.sort_inplace(out)
+        n = out.numel()
+        return ShardResult(out, 0, torch.tensor([[n]], dtype=torch.int64))
+
+    # 1. bucket b = keys whose top msb_bits equal b, contiguous, in input order
+    parted, counts = backend.msb_partition(local_keys, msb_bits)
+    counts = counts.to(torch.int64)
+
+    # 2. everyone learns the full count matrix (world x world words)
+    matrix = torch.empty(world * world, dtype=torch.int64, device=counts.device)
+    dist.all_gather_into_tensor(matrix, counts.contiguous(), group=group)
+    matrix_host = matrix.cpu().view(world, world)          # split sizes are host-side arguments
+    send_sizes = [int(x) for x in matrix_host[rank]]
+    recv_sizes = [int(x) for x in matrix_host[:, rank]]
+
+    # 3. one variable all-to-all
+    received = backend.empty_like(parted, sum(recv_sizes))
+    dist.all_to_all_single(received, parted, output_split_sizes=recv_sizes, input_split_sizes=send_sizes, group=group)
+
+    # 4. local LSD sort (the top bits are constant within a rank; the passes still run on all 32)
+    backend.sort_inplace(received)
+    offset = int(matrix_host[:, :rank].sum())
+    return ShardResult(received, offset, matrix_host)
