@@ -170,6 +170,23 @@ LSDSORT_API const char* lsdsort_last_hip_error_string(void);
 LSDSORT_API const char* lsdsort_version(void);
 /* Number of usable devices (gfx950) visible to this process; 0 if none.  Never fails. */
 LSDSORT_API int lsdsort_device_count(void);
+/* One-time per-device set-up (architecture check + the LDS-atomic probe below); implicit in
+ * the first compute call, explicit here so that it can be kept out of a graph capture. */
+LSDSORT_API int lsdsort_prepare_device(void);
+/* How the rank-and-scatter kernel ranks a key among the same-digit keys of its wavefront:
+ *   0  peer masks (wave ballots for digits <= 4 bits, a wave-private LDS OR for 8 bits):
+ *      correct on any hardware;
+ *   2  one returning LDS add per key, which needs the LDS to serve the colliding lanes of one
+ *      wave instruction in lane order; the library verifies that on the device (a probe
+ *      kernel at set-up) and silently uses form 0 if it does not hold;
+ *  -1  (default) form 2 for 8-bit digits when the probe passes, form 0 otherwise.
+ * lsdsort_rank_method reports the form a sort with this radix will use on the current device. */
+LSDSORT_API int lsdsort_set_rank_method(int method);
+LSDSORT_API int lsdsort_rank_method(int radix_bits);
+/* XCD affinity of the rank-and-scatter kernel: C consecutive tiles are claimed by workgroups of
+ * one XCD so that neighbouring runs merge in one L2; 0 disables, default 16,
+ * at most 64.  Speed only: results and forward progress never depend on it. */
+LSDSORT_API int lsdsort_set_xcd_chunk(int chunk);
 /* Runtime tuning knob for experiments: selects among the compiled tile shapes (see
  * DESIGN.md); -1 restores the default.  Returns LSDSORT_ERR_INVALID_ARG if unknown. */
 LSDSORT_API int lsdsort_set_tile_config(int radix_bits, int config_id);

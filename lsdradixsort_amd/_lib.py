@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblsdsort.so")
+# LSDSORT_LIB lets diagnostic tools load an instrumented build; the package default is the product.
+LIB_PATH = os.environ.get("LSDSORT_LIB") or os.path.join(_HERE, "liblsdsort.so")
 
 c_u32p = ctypes.c_void_p   # device or host addresses are passed as integers
 c_size = ctypes.c_size_t
@@ -62,6 +63,10 @@ SIGNATURES = {
     "lsdsort_version": (ctypes.c_char_p, []),
     "lsdsort_device_count": (c_int, []),
     "lsdsort_set_tile_config": (c_int, [c_int, c_int]),
+    "lsdsort_prepare_device": (c_int, []),
+    "lsdsort_set_xcd_chunk": (c_int, [c_int]),
+    "lsdsort_set_rank_method": (c_int, [c_int]),
+    "lsdsort_rank_method": (c_int, [c_int]),
 }
 
 _lib = None

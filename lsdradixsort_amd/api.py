@@ -19,7 +19,7 @@ from .errors import LSDSORT_ALGO_ONESWEEP, LSDSORT_ALGO_STAGED, check
 __all__ = [
     "sort", "sort_pairs", "to_device", "to_host", "workspace_bytes", "GPULSDRadixSort",
     "GPULSDRadixSortTimed", "BuildHistograms", "BuildOffsets", "RankScatter", "DigitHistograms",
-    "MSBPartition", "tile_keys", "set_tile_config", "LSDSORT_ALGO_ONESWEEP", "LSDSORT_ALGO_STAGED",
+    "MSBPartition", "tile_keys", "set_tile_config", "set_rank_method", "rank_method", "set_xcd_chunk", "LSDSORT_ALGO_ONESWEEP", "LSDSORT_ALGO_STAGED",
 ]
 
 
@@ -101,6 +101,23 @@ def tile_keys(radix_bits: int) -> int:
 
 def set_tile_config(radix_bits: int, config_id: int) -> None:
     check(lib().lsdsort_set_tile_config(radix_bits, config_id), "lsdsort_set_tile_config")
+
+
+def set_xcd_chunk(chunk: int) -> None:
+    """Consecutive tiles kept on one XCD by the rank-and-scatter kernel (0 = off; speed only)."""
+    check(lib().lsdsort_set_xcd_chunk(chunk), "lsdsort_set_xcd_chunk")
+
+
+def set_rank_method(method: int) -> None:
+    """-1 auto, 0 peer-mask forms only, 2 returning-LDS-add wherever the device probe passed."""
+    check(lib().lsdsort_set_rank_method(method), "lsdsort_set_rank_method")
+
+
+def rank_method(radix_bits: int) -> int:
+    m = lib().lsdsort_rank_method(radix_bits)
+    if m < 0:
+        check(m, "lsdsort_rank_method")
+    return int(m)
 
 
 # ------------------------------------------------------------------------------ device-resident sort

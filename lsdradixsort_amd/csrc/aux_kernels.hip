@@ -351,13 +351,73 @@ hipError_t launch_store_u64(uint64_t* out, uint64_t value, hipStream_t stream)
 }
 
 // ------------------------------------------------------------------------------------------
+// Probe for kRankLdsAdd: does a returning LDS add, issued by the 64 lanes of one wave
+// instruction onto colliding addresses, return its old values in lane order?  Each wave
+// compares ds_add_rtn_u32 against the ballot-derived stable rank over collision patterns from
+// "none" to "all 64 lanes on one word", with every CU busy.  Any disagreement clears *ok.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) probe_lds_add_kernel(uint32_t iters, uint32_t* mismatches)
+{
+    __shared__ uint32_t s_cnt_raw[8 * 256];
+    __shared__ uint32_t s_ref_raw[8 * 256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    volatile lds_u32* cnt = (volatile lds_u32*)s_cnt_raw + wave * 256;
+    volatile lds_u32* ref = (volatile lds_u32*)s_ref_raw + wave * 256;
+    for (uint32_t j = lane; j < 256; j += 64) {
+        cnt[j] = 0;
+        ref[j] = 0;
+    }
+    uint32_t bad = 0;
+    for (uint32_t it = 0; it < iters; it++) {
+        uint32_t h = (it * 0x9E3779B9u) ^ (blockIdx.x * 0x85EBCA6Bu) ^ (tid * 0xC2B2AE35u);
+        h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+        uint32_t d;
+        switch ((it + blockIdx.x) % 6u) {
+            case 0: d = h & 0xFFu; break;
+            case 1: d = h & 0x0Fu; break;
+            case 2: d = h & 0x01u; break;
+            case 3: d = 7u; break;
+            case 4: d = (lane >> 2) & 0xFFu; break;
+            default: d = (h & 0xFFu) * ((h >> 8) & 1u); break;
+        }
+        const uint64_t peers = match_ballot<8>(d);
+        const uint32_t before = ref[d];
+        const uint32_t expect = mbcnt_add(peers, before);
+        const uint32_t old = __hip_atomic_fetch_add((lds_u32*)&cnt[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (old != expect) bad++;
+        if (expect == before) ref[d] = popc64_add(peers, before);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+hipError_t probe_lds_add_lane_order(bool* ok, hipStream_t stream)
+{
+    *ok = false;
+    uint32_t* d_bad = nullptr;
+    hipError_t e = hipMalloc(&d_bad, sizeof(uint32_t));
+    if (e != hipSuccess) return e;
+    uint32_t h_bad = 1;
+    e = hipMemsetAsync(d_bad, 0, sizeof(uint32_t), stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(probe_lds_add_kernel, dim3(256 * 3), dim3(512), 0, stream, 600u, d_bad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_bad);
+    if (e == hipSuccess) *ok = (h_bad == 0);
+    return e;
+}
+
+// ------------------------------------------------------------------------------------------
 // rank-and-scatter dispatch: per-radix translation units hold the instantiations.
 // ------------------------------------------------------------------------------------------
-hipError_t launch_rank_scatter_r8(int shape_id, bool chained, const PassParams& p, hipStream_t stream);
-hipError_t launch_rank_scatter_r4(int shape_id, bool chained, const PassParams& p, hipStream_t stream);
-hipError_t launch_rank_scatter_small(int radix_bits, bool chained, const PassParams& p, hipStream_t stream);
+hipError_t launch_rank_scatter_r8(int shape_id, int rank_method, bool chained, const PassParams& p, hipStream_t stream);
+hipError_t launch_rank_scatter_r4(int shape_id, int rank_method, bool chained, const PassParams& p, hipStream_t stream);
+hipError_t launch_rank_scatter_small(int radix_bits, int rank_method, bool chained, const PassParams& p, hipStream_t stream);
 
-static const TileShape kShapesR8[] = {{512, 16}, {256, 16}, {1024, 16}};
+static const TileShape kShapesR8[] = {{512, 16}, {256, 16}, {1024, 16}, {512, 32}, {1024, 32}, {512, 32}, {512, 64},
+                                      {512, 64}, {1024, 32}, {1024, 32}, {256, 64}};
 static const TileShape kShapesR4[] = {{512, 16}, {256, 16}};
 static const TileShape kShapesSmall[] = {{256, 16}};
 
@@ -371,20 +431,18 @@ int tile_shapes(int radix_bits, const TileShape** out)
     }
 }
 
-hipError_t launch_rank_scatter(int radix_bits, const TileShape& shape, bool chained, const PassParams& p,
-                               hipStream_t stream)
+hipError_t launch_rank_scatter(int radix_bits, const TileShape& shape, int rank_method, bool chained,
+                               const PassParams& p, hipStream_t stream)
 {
     const TileShape* shapes = nullptr;
     const int count = tile_shapes(radix_bits, &shapes);
-    int id = -1;
-    for (int i = 0; i < count; i++)
-        if (shapes[i].threads == shape.threads && shapes[i].keys_per_thread == shape.keys_per_thread) id = i;
-    if (id < 0) return hipErrorInvalidValue;
+    const int id = (int)(&shape - shapes);   // shapes are identified by their table slot
+    if (id < 0 || id >= count) return hipErrorInvalidValue;
     if (p.num_tiles == 0) return hipSuccess;
     switch (radix_bits) {
-        case 8: return launch_rank_scatter_r8(id, chained, p, stream);
-        case 4: return launch_rank_scatter_r4(id, chained, p, stream);
-        default: return launch_rank_scatter_small(radix_bits, chained, p, stream);
+        case 8: return launch_rank_scatter_r8(id, rank_method, chained, p, stream);
+        case 4: return launch_rank_scatter_r4(id, rank_method, chained, p, stream);
+        default: return launch_rank_scatter_small(radix_bits, rank_method, chained, p, stream);
     }
 }
 

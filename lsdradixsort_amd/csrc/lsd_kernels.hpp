@@ -32,16 +32,30 @@ struct PassParams {
     // chained (onesweep) form
     const uint32_t* digit_base;  // [2^R] exclusive scan of the global digit counts of this pass
     uint32_t* status;            // [num_tiles][2^R] tile-status words (lsd_device.hpp)
-    uint32_t* tile_counter;      // dynamic tile id dispenser for this pass (zeroed)
+    uint32_t* tile_counter;      // arrival ticket dispenser for this pass (zeroed)
+    uint32_t* chunk_counters;    // [groups][8] per-XCD chunk claim counters for this pass (zeroed)
     uint32_t parity;             // pass parity for the status codes
     // staged form
     const uint32_t* global_off;  // [num_tiles][2^R] digit-major exclusive scan, block-major
     uint32_t* fault;             // workspace fault word
+    uint32_t xcd_chunk;          // C: consecutive tiles kept on one XCD (0 = no affinity)
+    unsigned long long* stats;   // diagnostic builds only (LSD_PHASE_STATS); null otherwise
+};
+
+// How stage 3 ranks a key among the same-digit keys of its wave (rank_scatter.hpp).
+enum RankMethod : int {
+    kRankBallot = 0,   // R wave-wide ballots                      (any hardware)
+    kRankLdsOr = 1,    // peer mask through a wave-private LDS OR   (any hardware)
+    kRankLdsAdd = 2,   // one returning LDS add per key; needs lane-ordered LDS atomics (probed)
 };
 
 // Stage 3.  chained=true: tile bases by decoupled look-back; false: read from global_off.
-hipError_t launch_rank_scatter(int radix_bits, const TileShape& shape, bool chained,
+// rank_method: kRankLdsAdd, or any other value for the mask form suited to the digit width.
+hipError_t launch_rank_scatter(int radix_bits, const TileShape& shape, int rank_method, bool chained,
                                const PassParams& p, hipStream_t stream);
+
+// Device probe of the property kRankLdsAdd relies on: returns hipSuccess and sets *ok.
+hipError_t probe_lds_add_lane_order(bool* ok, hipStream_t stream);
 
 // Stage 1, onesweep: all `groups` digit histograms (digit g at bit shift0 + g*radix_bits) in
 // one read; hist[g][d] must be zero on entry.

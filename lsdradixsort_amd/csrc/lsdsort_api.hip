@@ -14,6 +14,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 #include "lsd_kernels.hpp"
 
@@ -37,6 +38,7 @@ thread_local hipError_t g_last_hip = hipSuccess;
 constexpr size_t kAlign = 256;
 constexpr size_t kControlBytes = 256;            // u32[64]: [0] fault word, [32..63] tile counters
 constexpr size_t kControlCounterWord = 32;
+constexpr uint32_t kMaxXcdChunk = 64;
 constexpr size_t kDigitTableBytes = 4096;        // up to (32/R) x 2^R u32 counters, R <= 8
 
 size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
@@ -59,6 +61,8 @@ const TileShape* current_shape(int radix_bits)
 struct Layout {
     size_t control = 0;      // fault word + per-pass tile counters
     size_t digit_hist = 0;   // onesweep: [P][H] counts
+    size_t chunk_counters = 0;  // onesweep: [P][groups][8] per-XCD chunk claim counters
+    uint32_t groups = 0;
     size_t status = 0;       // onesweep: [tiles][H] tile-status words
     size_t zero_bytes = 0;
     size_t digit_base = 0;   // onesweep: [P][H] exclusive scans
@@ -83,6 +87,9 @@ Layout make_layout(size_t n, int radix_bits, bool pairs, int algorithm, const Ti
     if (algorithm == LSDSORT_ALGO_ONESWEEP) {
         L.digit_hist = off;
         off += kDigitTableBytes;
+        L.groups = L.tiles / 8u + 1;   // groups of 8*C tiles; sized for C = 1 so the knob never changes the layout
+        L.chunk_counters = off;
+        off = align_up(off + (size_t)(32 / radix_bits) * L.groups * 8u * sizeof(uint32_t));
         L.status = off;
         off = align_up(off + (size_t)L.tiles * bins * sizeof(uint32_t));
         L.zero_bytes = off;
@@ -107,7 +114,17 @@ Layout make_layout(size_t n, int radix_bits, bool pairs, int algorithm, const Ti
     return L;
 }
 
-int check_device_ready()
+// Per-device facts learned once: is it gfx950, and does it serve colliding LDS atomics of one
+// wave instruction in lane order (needed by kRankLdsAdd)?  The probe allocates and synchronises,
+// so it runs once per device, on first use or from lsdsort_prepare_device(), never per sort.
+struct DeviceState {
+    std::atomic<int> state{0};   // 0 unknown, 1 usable, -1 not gfx950
+    bool lds_add_in_lane_order = false;
+};
+DeviceState g_device[64];
+std::mutex g_device_mutex;
+
+int check_device_ready(int* device_out = nullptr)
 {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
@@ -115,25 +132,54 @@ int check_device_ready()
         return LSDSORT_ERR_NO_DEVICE;
     }
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) {
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
         (void)hipGetLastError();
         return LSDSORT_ERR_NO_DEVICE;
     }
-    static thread_local int checked_dev = -1;
-    if (checked_dev != dev) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-            (void)hipGetLastError();
-            return LSDSORT_ERR_NO_DEVICE;
+    if (device_out) *device_out = dev;
+    DeviceState& st = g_device[dev];
+    int state = st.state.load(std::memory_order_acquire);
+    if (state == 0) {
+        std::lock_guard<std::mutex> lock(g_device_mutex);
+        state = st.state.load(std::memory_order_acquire);
+        if (state == 0) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+                (void)hipGetLastError();
+                return LSDSORT_ERR_NO_DEVICE;
+            }
+            if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {   // code objects are gfx950 only
+                st.state.store(-1, std::memory_order_release);
+                return LSDSORT_ERR_NO_DEVICE;
+            }
+            bool ok = false;
+            LSD_HIP(lsd::probe_lds_add_lane_order(&ok, nullptr));
+            st.lds_add_in_lane_order = ok;
+            st.state.store(1, std::memory_order_release);
+            state = 1;
         }
-        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return LSDSORT_ERR_NO_DEVICE;   // code objects are gfx950 only
-        checked_dev = dev;
     }
-    return LSDSORT_OK;
+    return state == 1 ? LSDSORT_OK : LSDSORT_ERR_NO_DEVICE;
+}
+
+std::atomic<uint32_t> g_xcd_chunk{16};   // consecutive tiles kept on one XCD
+std::atomic<unsigned long long*> g_stats{nullptr};   // diagnostic builds only
+std::atomic<int> g_rank_setting{-1};   // -1 auto, 0 mask forms only, 2 returning LDS add wherever probed ok
+
+// The rank form a sort on `dev` with this radix will use.
+int resolve_rank_method(int dev, int radix_bits)
+{
+    const int setting = g_rank_setting.load(std::memory_order_relaxed);
+    const bool ok = g_device[dev].lds_add_in_lane_order;
+    if (setting == 0 || !ok) return radix_bits > 4 ? lsd::kRankLdsOr : lsd::kRankBallot;
+    if (setting == 2) return lsd::kRankLdsAdd;
+    // auto: one LDS op per key beats eight ballots or an OR round trip for wide digits; for
+    // narrow digits most lanes collide on a few counters and the ballots are cheaper.
+    return radix_bits > 4 ? lsd::kRankLdsAdd : lsd::kRankBallot;
 }
 
 struct StageEvents {
-    hipEvent_t ev[LSDSORT_MAX_PASSES + 4];
+    hipEvent_t ev[3 * LSDSORT_MAX_PASSES + 4];
     int count = 0;
     bool enabled = false;
     hipStream_t stream = nullptr;
@@ -158,8 +204,9 @@ struct StageEvents {
         if (s__ != LSDSORT_OK) return s__; \
     } while (0)
 
-// The pass loop.  Marks (when timing): 0 start | 1 after clear | 2 after stage 1 | 3 after stage 2 |
-// 4+p after pass p   (staged: stages 1 and 2 are inside the pass; marks 2 and 3 coincide with 1).
+// The pass loop.  Marks (when timing), onesweep: 0 start | 1 after clear | 2 after stage 1 |
+// 3 after stage 2 | 4+p after pass p.  Staged: 0 start | 1 after clear | 2, 3 (empty) | then per
+// pass three marks: after its histogram, after its offset scan, after its scatter.
 int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, size_t n, int radix_bits,
              int algorithm, hipStream_t stream, StageEvents* ev, lsdsort_timing* timing)
 {
@@ -168,7 +215,9 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     if (n > LSDSORT_MAX_KEYS) return LSDSORT_ERR_TOO_LARGE;
     if (n == 0) return LSDSORT_OK;
     if (!d_keys) return LSDSORT_ERR_INVALID_ARG;
-    LSD_TRY(check_device_ready());
+    int dev = 0;
+    LSD_TRY(check_device_ready(&dev));
+    const int rank_method = resolve_rank_method(dev, radix_bits);
     const TileShape* shape = current_shape(radix_bits);
     if (!shape) return LSDSORT_ERR_INVALID_ARG;
     const bool pairs = d_vals != nullptr;
@@ -219,22 +268,27 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
         p.shift = (uint32_t)(pass * radix_bits);
         p.num_tiles = L.tiles;
         p.fault = control;
+        p.xcd_chunk = g_xcd_chunk.load(std::memory_order_relaxed);
+        p.stats = g_stats.load(std::memory_order_relaxed);
         if (algorithm == LSDSORT_ALGO_ONESWEEP) {
             p.digit_base = digit_base + (size_t)pass * bins;
             p.status = reinterpret_cast<uint32_t*>(ws + L.status);
             p.tile_counter = control + kControlCounterWord + pass;
+            p.chunk_counters = reinterpret_cast<uint32_t*>(ws + L.chunk_counters) + (size_t)pass * L.groups * 8u;
             p.parity = (uint32_t)(pass & 1);
-            LSD_HIP(lsd::launch_rank_scatter(radix_bits, *shape, true, p, stream));
+            LSD_HIP(lsd::launch_rank_scatter(radix_bits, *shape, rank_method, true, p, stream));
         } else {
             uint32_t* tile_hist = reinterpret_cast<uint32_t*>(ws + L.tile_hist);
             uint32_t* tile_global = reinterpret_cast<uint32_t*>(ws + L.tile_global);
             uint32_t* scratch = reinterpret_cast<uint32_t*>(ws + L.scratch);
             LSD_HIP(lsd::launch_tile_histograms(radix_bits, *shape, src, (uint32_t)n, p.shift, tile_hist, stream));
+            if (ev) LSD_TRY(ev->mark());
             // local offsets are recomputed inside the rank-and-scatter kernel (it needs them for
             // ranking anyway); only the global table is materialised here.
             LSD_HIP(lsd::launch_tile_offsets(radix_bits, tile_hist, nullptr, tile_global, L.tiles, scratch, stream));
+            if (ev) LSD_TRY(ev->mark());
             p.global_off = tile_global;
-            LSD_HIP(lsd::launch_rank_scatter(radix_bits, *shape, false, p, stream));
+            LSD_HIP(lsd::launch_rank_scatter(radix_bits, *shape, rank_method, false, p, stream));
         }
         if (ev) LSD_TRY(ev->mark());
         uint32_t* t = src; src = dst; dst = t;
@@ -367,6 +421,41 @@ int lsdsort_set_tile_config(int radix_bits, int config_id)
     return LSDSORT_OK;
 }
 
+int lsdsort_set_xcd_chunk(int chunk)
+{
+    if (chunk < 0 || chunk > (int)kMaxXcdChunk) return LSDSORT_ERR_INVALID_ARG;
+    g_xcd_chunk.store((uint32_t)chunk, std::memory_order_relaxed);
+    return LSDSORT_OK;
+}
+
+#ifdef LSD_PHASE_STATS
+LSDSORT_API int lsdsort_debug_set_stats(unsigned long long* d_stats)
+{
+    g_stats.store(d_stats, std::memory_order_relaxed);
+    return LSDSORT_OK;
+}
+#endif
+
+int lsdsort_prepare_device(void)
+{
+    return check_device_ready();
+}
+
+int lsdsort_set_rank_method(int method)
+{
+    if (method != -1 && method != 0 && method != 2) return LSDSORT_ERR_INVALID_ARG;
+    g_rank_setting.store(method, std::memory_order_relaxed);
+    return LSDSORT_OK;
+}
+
+int lsdsort_rank_method(int radix_bits)
+{
+    if (radix_bits < 1 || radix_bits > 8) return LSDSORT_ERR_INVALID_ARG;
+    int dev = 0;
+    LSD_TRY(check_device_ready(&dev));
+    return resolve_rank_method(dev, radix_bits);
+}
+
 size_t lsdsort_tile_keys(int radix_bits)
 {
     const TileShape* shape = (radix_bits >= 1 && radix_bits <= 8) ? current_shape(radix_bits) : nullptr;
@@ -431,8 +520,21 @@ int lsdsort_u32_device_timed(uint32_t* d_keys, uint32_t* d_vals, void* d_workspa
             LSD_HIP(hipEventElapsedTime(&out->clear_ms, ev.ev[0], ev.ev[1]));
             LSD_HIP(hipEventElapsedTime(&out->histogram_ms, ev.ev[1], ev.ev[2]));
             LSD_HIP(hipEventElapsedTime(&out->scan_ms, ev.ev[2], ev.ev[3]));
-            for (int p = 0; p + 4 < ev.count && p < LSDSORT_MAX_PASSES; p++)
-                LSD_HIP(hipEventElapsedTime(&out->scatter_ms[p], ev.ev[3 + p], ev.ev[4 + p]));
+            if (algorithm == LSDSORT_ALGO_ONESWEEP) {
+                for (int p = 0; p + 4 < ev.count && p < LSDSORT_MAX_PASSES; p++)
+                    LSD_HIP(hipEventElapsedTime(&out->scatter_ms[p], ev.ev[3 + p], ev.ev[4 + p]));
+            } else {
+                out->histogram_ms = 0.f;
+                out->scan_ms = 0.f;
+                for (int p = 0; 3 * p + 6 < ev.count && p < LSDSORT_MAX_PASSES; p++) {
+                    float h = 0.f, s = 0.f;
+                    LSD_HIP(hipEventElapsedTime(&h, ev.ev[3 + 3 * p], ev.ev[4 + 3 * p]));
+                    LSD_HIP(hipEventElapsedTime(&s, ev.ev[4 + 3 * p], ev.ev[5 + 3 * p]));
+                    LSD_HIP(hipEventElapsedTime(&out->scatter_ms[p], ev.ev[5 + 3 * p], ev.ev[6 + 3 * p]));
+                    out->histogram_ms += h;
+                    out->scan_ms += s;
+                }
+            }
             return LSDSORT_OK;
         };
         status = finish();
@@ -497,7 +599,8 @@ int lsdsort_rank_scatter_u32_device(const uint32_t* d_in, uint32_t* d_out, const
     if (n > LSDSORT_MAX_KEYS) return LSDSORT_ERR_TOO_LARGE;
     if (n == 0) return LSDSORT_OK;
     if (!d_in || !d_out || !d_global || ((d_vals_in == nullptr) != (d_vals_out == nullptr))) return LSDSORT_ERR_INVALID_ARG;
-    LSD_TRY(check_device_ready());
+    int dev = 0;
+    LSD_TRY(check_device_ready(&dev));
     const TileShape* shape = current_shape(radix_bits);
     PassParams p{};
     p.in = d_in;
@@ -508,7 +611,8 @@ int lsdsort_rank_scatter_u32_device(const uint32_t* d_in, uint32_t* d_out, const
     p.shift = (uint32_t)(bit_group * radix_bits);
     p.num_tiles = (uint32_t)((n + shape->tile() - 1) / shape->tile());
     p.global_off = d_global;
-    LSD_HIP(lsd::launch_rank_scatter(radix_bits, *shape, false, p, static_cast<hipStream_t>(hip_stream)));
+    LSD_HIP(lsd::launch_rank_scatter(radix_bits, *shape, resolve_rank_method(dev, radix_bits), false, p,
+                                     static_cast<hipStream_t>(hip_stream)));
     return LSDSORT_OK;
 }
 
@@ -540,7 +644,8 @@ int lsdsort_msb_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size
     if (msb_bits < 0 || msb_bits > 3 || !d_counts) return LSDSORT_ERR_INVALID_ARG;
     if (n > LSDSORT_MAX_KEYS) return LSDSORT_ERR_TOO_LARGE;
     if (n > 0 && (!d_in || !d_out || d_in == d_out)) return LSDSORT_ERR_INVALID_ARG;
-    LSD_TRY(check_device_ready());
+    int dev = 0;
+    LSD_TRY(check_device_ready(&dev));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const MsbLayout L = make_msb_layout(n, msb_bits);
     if (!d_workspace || (reinterpret_cast<uintptr_t>(d_workspace) & (kAlign - 1)) || workspace_bytes < L.total)
@@ -572,7 +677,7 @@ int lsdsort_msb_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size
         p.tile_counter = control + kControlCounterWord;
         p.parity = 0;
         p.fault = control;
-        LSD_HIP(lsd::launch_rank_scatter(msb_bits, *current_shape(msb_bits), true, p, stream));
+        LSD_HIP(lsd::launch_rank_scatter(msb_bits, *current_shape(msb_bits), resolve_rank_method(dev, msb_bits), true, p, stream));
     }
     LSD_HIP(lsd::launch_widen_counts(hist, d_counts, bins, stream));
     return LSDSORT_OK;

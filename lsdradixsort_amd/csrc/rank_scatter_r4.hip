@@ -4,11 +4,11 @@
 
 namespace lsd {
 
-hipError_t launch_rank_scatter_r4(int shape_id, bool chained, const PassParams& p, hipStream_t stream)
+hipError_t launch_rank_scatter_r4(int shape_id, int rank_method, bool chained, const PassParams& p, hipStream_t stream)
 {
     switch (shape_id) {
-        case 0: return launch_rank_scatter_shape<4, 512, 16>(chained, p, stream);
-        case 1: return launch_rank_scatter_shape<4, 256, 16>(chained, p, stream);
+        case 0: return launch_rank_scatter_shape<4, 512, 16>(rank_method, chained, p, stream);
+        case 1: return launch_rank_scatter_shape<4, 256, 16>(rank_method, chained, p, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -4,12 +4,12 @@
 
 namespace lsd {
 
-hipError_t launch_rank_scatter_small(int radix_bits, bool chained, const PassParams& p, hipStream_t stream)
+hipError_t launch_rank_scatter_small(int radix_bits, int rank_method, bool chained, const PassParams& p, hipStream_t stream)
 {
     switch (radix_bits) {
-        case 1: return launch_rank_scatter_shape<1, 256, 16>(chained, p, stream);
-        case 2: return launch_rank_scatter_shape<2, 256, 16>(chained, p, stream);
-        case 3: return launch_rank_scatter_shape<3, 256, 16>(chained, p, stream);
+        case 1: return launch_rank_scatter_shape<1, 256, 16>(rank_method, chained, p, stream);
+        case 2: return launch_rank_scatter_shape<2, 256, 16>(rank_method, chained, p, stream);
+        case 3: return launch_rank_scatter_shape<3, 256, 16>(rank_method, chained, p, stream);
         default: return hipErrorInvalidValue;
     }
 }

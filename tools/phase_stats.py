@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Where a rank-and-scatter tile spends its time (diagnostic build: make -C lsdradixsort_amd/csrc stats).
+Run with LSDSORT_LIB=lsdradixsort_amd/liblsdsort_stats.so on the GPU box."""
+import argparse, ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import lsdradixsort_amd as lsd
+from bench import mt19937_keys
+ap = argparse.ArgumentParser()
+ap.add_argument("--cfgs", type=int, nargs="*", default=[0])
+ap.add_argument("--chunk", type=int, nargs="*", default=[0, 16])
+ap.add_argument("--algos", type=int, nargs="*", default=[0, 1])
+ap.add_argument("--mask", type=lambda x: int(x, 0), default=0xFFFFFFFF)
+a = ap.parse_args()
+L = ctypes.CDLL(lsd.LIB_PATH)
+n = 1 << 28
+master = lsd.to_device(mt19937_keys(n, 0) & np.uint32(a.mask))
+stats = torch.zeros((1 << 17) * 10, dtype=torch.int64, device="cuda")
+L.lsdsort_debug_set_stats.argtypes = [ctypes.c_void_p]
+L.lsdsort_debug_set_stats(stats.data_ptr())
+names = ["ticket", "keyload", "rank", "scan+pub", "ldswrite", "lookback", "readback+store"]
+for cfg in a.cfgs:
+    lsd.set_tile_config(8, cfg)
+    for algo in a.algos:
+        for C in a.chunk:
+            lsd.set_xcd_chunk(C)
+            ws = lsd.alloc_workspace(n, 8, False, algo)
+            k = master.clone(); lsd.GPULSDRadixSort(k, 8, algorithm=algo, workspace=ws); torch.cuda.synchronize()
+            stats.zero_()
+            k = master.clone()
+            tm = lsd.GPULSDRadixSortTimed(k, 8, algorithm=algo, workspace=ws)
+            assert tm["tiles"] <= (1 << 17)
+            rec = stats.cpu().numpy().astype(np.float64)[: tm["tiles"] * 10].reshape(-1, 10)   # last pass's records
+            s = np.zeros(16); s[14] = rec[:, 7].mean(); s[13] = rec[:, 8].mean(); tiles = 1
+            per = rec[:, :7].mean(axis=0) / 100.0   # us per tile (100 MHz clock)
+            print(f"cfg={cfg} tile={tm['tile_keys']} algo={algo} C={C:2d} scatter/pass={np.mean(tm['scatter_ms']):.3f} ms | " +
+                  " ".join(f"{nm}={v:5.2f}" for nm, v in zip(names, per)) + f" | sum={per.sum():5.2f} us/tile refills/tile={s[14]/tiles:.2f} emptypolls/tile={s[13]/tiles:.2f}", flush=True)
