@@ -152,6 +152,184 @@ hipError_t launch_scan_digit_counts(int radix_bits, int groups, const uint32_t* 
 }
 
 // ------------------------------------------------------------------------------------------
+// Stage 1 (onesweep with regions): joint counts for every pass in ONE read.
+//
+// For pass p the rank-and-scatter kernel wants, per region x of that pass's input, the histogram
+// of digit p (lsd_kernels.hpp, "Regions").  Region membership is a key field too -- the top three
+// bits of digit p-1 -- so (digit p, region) is one (R+3)-bit field of the key, bits
+// [R*p - 3, R*p + R), and counting it is one v_bfe_u32 and one LDS atomic per key per pass, the
+// same work as a plain digit histogram with a table 8x as large.  Pass 0 has no previous digit:
+// its regions are by position, uniform for a whole 1024-key chunk.
+// ------------------------------------------------------------------------------------------
+template <int R>
+__global__ void __launch_bounds__(kHistThreads) joint_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                                       uint32_t region0_keys,
+                                                                       uint32_t* __restrict__ joint,
+                                                                       uint32_t vec_chunks)
+{
+    constexpr int P = 32 / R;
+    constexpr int F = (1 << R) * kRegions;   // fields per pass
+    __shared__ uint32_t s_joint[P * F];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t j = tid; j < (uint32_t)(P * F); j += kHistThreads) s_joint[j] = 0;
+    __syncthreads();
+
+    auto count_key = [&](uint32_t k, uint32_t region0) {
+        atomicAdd(&s_joint[(digit_at<R>(k, 0) << 3) | region0], 1u);
+#pragma unroll
+        for (int p = 1; p < P; p++) atomicAdd(&s_joint[p * F + digit_at<R + 3>(k, (uint32_t)(R * p - 3))], 1u);
+    };
+
+    const uint4* __restrict__ keys4 = reinterpret_cast<const uint4*>(keys);
+    for (uint32_t c = blockIdx.x * kHistVecPerThread; c < vec_chunks; c += gridDim.x * kHistVecPerThread) {
+        uint4 v[kHistVecPerThread];
+#pragma unroll
+        for (int u = 0; u < kHistVecPerThread; u++) {
+            const uint32_t cc = c + u;
+            v[u] = cc < vec_chunks ? keys4[(size_t)cc * kHistThreads + tid] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < kHistVecPerThread; u++) {
+            if (c + u < vec_chunks) {
+                // region0_keys is a multiple of the 1024-key chunk, so the chunk is in one region
+                const uint32_t region0 = ((c + u) * (uint32_t)(kHistThreads * 4)) / region0_keys;
+                count_key(v[u].x, region0);
+                count_key(v[u].y, region0);
+                count_key(v[u].z, region0);
+                count_key(v[u].w, region0);
+            }
+        }
+    }
+    if (blockIdx.x == 0) {
+        const uint32_t tail_begin = vec_chunks * (kHistThreads * 4);
+        for (uint32_t i = tail_begin + tid; i < n; i += kHistThreads) count_key(keys[i], i / region0_keys);
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < (uint32_t)(P * F); j += kHistThreads) {
+        const uint32_t c = s_joint[j];
+        if (c) atomicAdd(&joint[j], c);
+    }
+}
+
+hipError_t launch_joint_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys,
+                                   uint32_t* joint, hipStream_t stream)
+{
+    if (region0_keys == 0 || region0_keys % (kHistThreads * 4) != 0) return hipErrorInvalidValue;
+    const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
+    const uint32_t vec_chunks = aligned ? n / (kHistThreads * 4) : 0;
+    uint32_t blocks = (vec_chunks + kHistVecPerThread - 1) / kHistVecPerThread;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    switch (radix_bits) {
+        case 4:
+            hipLaunchKernelGGL((joint_histograms_kernel<4>), dim3(blocks), dim3(kHistThreads), 0, stream, keys, n,
+                               region0_keys, joint, vec_chunks);
+            break;
+        case 8:
+            hipLaunchKernelGGL((joint_histograms_kernel<8>), dim3(blocks), dim3(kHistThreads), 0, stream, keys, n,
+                               region0_keys, joint, vec_chunks);
+            break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 2 (onesweep): every pass's region table from the counts.  One workgroup per pass:
+//   digit_base[d]      = exclusive scan over d of the digit totals          (.cu:38-41 / PrefixSum)
+//   base[x][d]         = digit_base[d] + counts of digit d in regions before x
+//   extents of pass p+1 = [digit_base[x*H/8], digit_base[(x+1)*H/8])   (regions = top bits of digit p)
+//   extents of pass 0   = [x*R0, (x+1)*R0) clipped to n
+// ------------------------------------------------------------------------------------------
+template <int REG>
+__global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __restrict__ counts, int bins, uint32_t n,
+                                                          uint32_t tile_keys, uint32_t region0_keys, int passes,
+                                                          uint32_t* __restrict__ tables, uint32_t table_words)
+{
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base[257];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const int pass = blockIdx.x;
+    const uint32_t* c = counts + (size_t)pass * bins * REG;
+    uint32_t* table = tables + (size_t)pass * table_words;
+    uint32_t per_region[REG];
+    uint32_t total = 0;
+    if (tid < (uint32_t)bins) {
+#pragma unroll
+        for (int x = 0; x < REG; x++) {
+            per_region[x] = c[tid * REG + x];
+            total += per_region[x];
+        }
+    }
+    uint32_t incl = wave_inclusive_scan(total, lane);
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    for (uint32_t w = 0; w < wave; w++) incl += s_wave[w];
+    const uint32_t digit_base = incl - total;
+    if (tid < (uint32_t)bins) {
+        s_base[tid] = digit_base;
+        uint32_t run = digit_base;
+#pragma unroll
+        for (int x = 0; x < kRegions; x++) {
+            table[kRegionHeaderWords + x * bins + tid] = run;
+            if (x < REG) run += per_region[x];
+        }
+    }
+    if (tid == 0) s_base[bins] = n;
+    __syncthreads();
+    // Extents.  Written by one thread: eight entries and their running tile offset.
+    if (tid == 0) {
+        auto write_extents = [&](uint32_t* t, auto start_of) {
+            uint32_t off = 0;
+            for (int x = 0; x < kRegions; x++) {
+                const uint32_t lo = start_of(x), hi = start_of(x + 1);
+                const uint32_t len = hi - lo;
+                const uint32_t tiles = (len + tile_keys - 1) / tile_keys;
+                t[x] = lo;
+                t[8 + x] = len;
+                t[16 + x] = tiles;
+                t[24 + x] = off;
+                off += tiles;
+            }
+        };
+        if (pass == 0) {
+            if (REG == 1) {
+                write_extents(table, [&](int x) { return x == 0 ? 0u : n; });
+            } else {
+                write_extents(table, [&](int x) {
+                    const unsigned long long e = (unsigned long long)x * region0_keys;
+                    return e < n ? (uint32_t)e : n;
+                });
+            }
+        }
+        if (pass + 1 < passes) {
+            uint32_t* next = tables + (size_t)(pass + 1) * table_words;
+            if (REG == 1 || bins < kRegions) {
+                write_extents(next, [&](int x) { return x == 0 ? 0u : n; });
+            } else {
+                const int per = bins / kRegions;
+                write_extents(next, [&](int x) { return s_base[x * per]; });
+            }
+        }
+    }
+}
+
+hipError_t launch_scan_regions(int radix_bits, int passes, int regions, const uint32_t* counts, uint32_t n,
+                               uint32_t tile_keys, uint32_t region0_keys, uint32_t* tables, hipStream_t stream)
+{
+    if (radix_bits < 1 || radix_bits > 8 || (regions != 1 && regions != kRegions)) return hipErrorInvalidValue;
+    const int bins = 1 << radix_bits;
+    const uint32_t words = (uint32_t)region_table_words(radix_bits);
+    if (regions == 1)
+        hipLaunchKernelGGL((scan_regions_kernel<1>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
+                           region0_keys, passes, tables, words);
+    else
+        hipLaunchKernelGGL((scan_regions_kernel<kRegions>), dim3(passes), dim3(256), 0, stream, counts, bins, n,
+                           tile_keys, region0_keys, passes, tables, words);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // Stage 1 (staged): per-tile digit counts h[tile][digit], BuildHistogramsKernel .cu:660-702.
 // One workgroup per tile; counters in LDS, one coalesced row written per tile.
 // ------------------------------------------------------------------------------------------
@@ -417,7 +595,7 @@ hipError_t launch_rank_scatter_r4(int shape_id, int rank_method, bool chained, c
 hipError_t launch_rank_scatter_small(int radix_bits, int rank_method, bool chained, const PassParams& p, hipStream_t stream);
 
 static const TileShape kShapesR8[] = {{512, 16}, {256, 16}, {1024, 16}, {512, 32}, {1024, 32}, {512, 32}, {512, 64},
-                                      {512, 64}, {1024, 32}, {1024, 32}, {256, 64}};
+                                      {512, 64}, {1024, 32}, {1024, 32}, {256, 64}, {512, 24}, {512, 20}, {1024, 16}};
 static const TileShape kShapesR4[] = {{512, 16}, {256, 16}};
 static const TileShape kShapesSmall[] = {{256, 16}};
 

@@ -20,6 +20,21 @@ struct TileShape {
 // Compiled tile shapes for a radix; index 0 is the default.  Returns the count.
 int tile_shapes(int radix_bits, const TileShape** out);
 
+// Regions.  A pass's input is split into kRegions contiguous regions whose digit histograms are
+// known before the pass starts, so each region carries its own chained scan over its own tiles
+// and no tile ever needs anything from another region.  Workgroups serve the region of their own
+// XCD first (hardware XCC_ID), which keeps neighbouring runs in one L2 and keeps each chain short.
+//   pass 0     : region x = positions [x*R0, (x+1)*R0), R0 a multiple of the tile size
+//   pass p >= 1: region x = keys whose digit p-1 has top three bits x -- contiguous in the
+//                array because pass p-1 just sorted on that digit; its histogram of digit p is
+//                a joint count of two key fields, so it is permutation-invariant and comes out
+//                of the same single upfront read as the plain digit histograms.
+// Radixes below 3 bits (and the multi-GPU partition) use one region, i.e. one chain.
+constexpr int kRegions = 8;
+// Per-pass region table, uint32 words: start[8] | len[8] | tiles[8] | tile_off[8] | base[8][2^R]
+constexpr int kRegionHeaderWords = 32;
+inline constexpr size_t region_table_words(int radix_bits) { return kRegionHeaderWords + (size_t)kRegions * ((size_t)1 << radix_bits); }
+
 // Everything one rank-and-scatter launch needs.
 struct PassParams {
     const uint32_t* in;
@@ -28,17 +43,16 @@ struct PassParams {
     uint32_t* vals_out;
     uint32_t n;
     uint32_t shift;            // bit_group * radix_bits
-    uint32_t num_tiles;
+    uint32_t num_tiles;        // grid size: chained = upper bound on the regions' tile counts
     // chained (onesweep) form
-    const uint32_t* digit_base;  // [2^R] exclusive scan of the global digit counts of this pass
+    const uint32_t* regions;     // this pass's region table (device, written by the scan kernel)
     uint32_t* status;            // [num_tiles][2^R] tile-status words (lsd_device.hpp)
-    uint32_t* tile_counter;      // arrival ticket dispenser for this pass (zeroed)
-    uint32_t* chunk_counters;    // [groups][8] per-XCD chunk claim counters for this pass (zeroed)
+    uint32_t* tickets;           // [kRegions] arrival ticket dispensers for this pass (zeroed)
     uint32_t parity;             // pass parity for the status codes
     // staged form
     const uint32_t* global_off;  // [num_tiles][2^R] digit-major exclusive scan, block-major
     uint32_t* fault;             // workspace fault word
-    uint32_t xcd_chunk;          // C: consecutive tiles kept on one XCD (0 = no affinity)
+    uint32_t xcd_chunk;          // staged form: consecutive tiles kept on one XCD (0 = no affinity)
     unsigned long long* stats;   // diagnostic builds only (LSD_PHASE_STATS); null otherwise
 };
 
@@ -65,6 +79,17 @@ hipError_t launch_digit_histograms(int radix_bits, int groups, uint32_t shift0, 
 // Stage 2, onesweep: base[g][d] = exclusive scan over d of hist[g][d], for every group.
 hipError_t launch_scan_digit_counts(int radix_bits, int groups, const uint32_t* hist, uint32_t* base,
                                     hipStream_t stream);
+
+// Stage 1, onesweep with regions (radix 4 and 8): joint[p][(digit_p << 3) | region_p(key)] for every
+// pass in one read; `region0_keys` is R0 (pass-0 regions are by position).  joint must be zero on entry.
+hipError_t launch_joint_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys,
+                                   uint32_t* joint, hipStream_t stream);
+
+// Stage 2, onesweep: region tables of every pass from the joint counts (`regions` = 8) or from
+// plain digit histograms (`regions` = 1; passes may then be 1 for the multi-GPU partition).
+// counts: [passes][2^R][regions]; tables: [passes][region_table_words(R)].
+hipError_t launch_scan_regions(int radix_bits, int passes, int regions, const uint32_t* counts, uint32_t n,
+                               uint32_t tile_keys, uint32_t region0_keys, uint32_t* tables, hipStream_t stream);
 
 // Stage 1, staged: hist[t][d] per tile (BuildHistogramsKernel, .cu:660-702).
 hipError_t launch_tile_histograms(int radix_bits, const TileShape& shape, const uint32_t* keys,

@@ -36,10 +36,21 @@ thread_local hipError_t g_last_hip = hipSuccess;
     } while (0)
 
 constexpr size_t kAlign = 256;
-constexpr size_t kControlBytes = 256;            // u32[64]: [0] fault word, [32..63] tile counters
-constexpr size_t kControlCounterWord = 32;
+constexpr size_t kControlBytes = 256;            // u32[64]: [0] fault word
 constexpr uint32_t kMaxXcdChunk = 64;
-constexpr size_t kDigitTableBytes = 4096;        // up to (32/R) x 2^R u32 counters, R <= 8
+
+// Radixes whose passes are split into 8 regions (lsd_kernels.hpp); narrower digits have no
+// three top bits to split on and run as one region.
+bool uses_regions(int radix_bits) { return radix_bits == 4 || radix_bits == 8; }
+
+// Pass-0 regions are by position: R0 keys each, a multiple of the tile (hence of the histogram
+// kernel's 1024-key chunk), eight of them covering n.
+uint32_t region0_keys(size_t n, size_t tile)
+{
+    const size_t per = (n + lsd::kRegions - 1) / lsd::kRegions;
+    const size_t tiles = (per + tile - 1) / tile;
+    return (uint32_t)((tiles ? tiles : 1) * tile);
+}
 
 size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
@@ -59,20 +70,22 @@ const TileShape* current_shape(int radix_bits)
 
 // Device workspace carve-up.  Everything before `zero_bytes` is cleared at the start of a sort.
 struct Layout {
-    size_t control = 0;      // fault word + per-pass tile counters
-    size_t digit_hist = 0;   // onesweep: [P][H] counts
-    size_t chunk_counters = 0;  // onesweep: [P][groups][8] per-XCD chunk claim counters
-    uint32_t groups = 0;
-    size_t status = 0;       // onesweep: [tiles][H] tile-status words
+    size_t control = 0;      // fault word
+    size_t tickets = 0;      // onesweep: [P][8] arrival ticket dispensers
+    size_t counts = 0;       // onesweep: [P][H][regions] joint / digit counts
+    size_t status = 0;       // onesweep: [rows][H] tile-status words
     size_t zero_bytes = 0;
-    size_t digit_base = 0;   // onesweep: [P][H] exclusive scans
+    size_t tables = 0;       // onesweep: [P] region tables
     size_t tile_hist = 0;    // staged: [tiles][H] counts, then local offsets in place
     size_t tile_global = 0;  // staged: [tiles][H] global offsets
     size_t scratch = 0;      // staged: strip sums
     size_t alt_keys = 0;
     size_t alt_vals = 0;
     size_t total = 0;
-    uint32_t tiles = 0;
+    uint32_t tiles = 0;      // ceil(n / tile)
+    uint32_t rows = 0;       // onesweep: status rows = grid size = tiles + one ragged tile per region
+    uint32_t region0 = 0;    // onesweep: keys per pass-0 region
+    int regions = 1;
 };
 
 Layout make_layout(size_t n, int radix_bits, bool pairs, int algorithm, const TileShape& shape)
@@ -80,21 +93,24 @@ Layout make_layout(size_t n, int radix_bits, bool pairs, int algorithm, const Ti
     Layout L;
     const size_t bins = (size_t)1 << radix_bits;
     const size_t tile = (size_t)shape.tile();
+    const size_t passes = 32 / radix_bits;
     L.tiles = (uint32_t)((n + tile - 1) / tile);
     size_t off = 0;
     L.control = off;
     off += kControlBytes;
     if (algorithm == LSDSORT_ALGO_ONESWEEP) {
-        L.digit_hist = off;
-        off += kDigitTableBytes;
-        L.groups = L.tiles / 8u + 1;   // groups of 8*C tiles; sized for C = 1 so the knob never changes the layout
-        L.chunk_counters = off;
-        off = align_up(off + (size_t)(32 / radix_bits) * L.groups * 8u * sizeof(uint32_t));
+        L.regions = uses_regions(radix_bits) ? lsd::kRegions : 1;
+        L.rows = L.tiles + (uint32_t)lsd::kRegions;
+        L.region0 = region0_keys(n, tile);
+        L.tickets = off;
+        off = align_up(off + passes * lsd::kRegions * sizeof(uint32_t));
+        L.counts = off;
+        off = align_up(off + passes * bins * (size_t)L.regions * sizeof(uint32_t));
         L.status = off;
-        off = align_up(off + (size_t)L.tiles * bins * sizeof(uint32_t));
+        off = align_up(off + (size_t)L.rows * bins * sizeof(uint32_t));
         L.zero_bytes = off;
-        L.digit_base = off;
-        off += kDigitTableBytes;
+        L.tables = off;
+        off = align_up(off + passes * lsd::region_table_words(radix_bits) * sizeof(uint32_t));
     } else {
         L.zero_bytes = off;
         L.tile_hist = off;
@@ -229,7 +245,6 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     uint32_t* alt_keys = reinterpret_cast<uint32_t*>(ws + L.alt_keys);
     uint32_t* alt_vals = pairs ? reinterpret_cast<uint32_t*>(ws + L.alt_vals) : nullptr;
     const int passes = 32 / radix_bits;
-    const uint32_t bins = 1u << radix_bits;
     if (timing) {
         timing->passes = passes;
         timing->tile_keys = shape->tile();
@@ -240,14 +255,18 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     LSD_HIP(hipMemsetAsync(ws, 0, L.zero_bytes, stream));
     if (ev) LSD_TRY(ev->mark());
 
-    uint32_t* digit_hist = nullptr;
-    uint32_t* digit_base = nullptr;
+    uint32_t* tables = nullptr;
+    const size_t table_words = lsd::region_table_words(radix_bits);
     if (algorithm == LSDSORT_ALGO_ONESWEEP) {
-        digit_hist = reinterpret_cast<uint32_t*>(ws + L.digit_hist);
-        digit_base = reinterpret_cast<uint32_t*>(ws + L.digit_base);
-        LSD_HIP(lsd::launch_digit_histograms(radix_bits, passes, 0, d_keys, (uint32_t)n, digit_hist, stream));
+        uint32_t* counts = reinterpret_cast<uint32_t*>(ws + L.counts);
+        tables = reinterpret_cast<uint32_t*>(ws + L.tables);
+        if (L.regions == lsd::kRegions)
+            LSD_HIP(lsd::launch_joint_histograms(radix_bits, d_keys, (uint32_t)n, L.region0, counts, stream));
+        else
+            LSD_HIP(lsd::launch_digit_histograms(radix_bits, passes, 0, d_keys, (uint32_t)n, counts, stream));
         if (ev) LSD_TRY(ev->mark());
-        LSD_HIP(lsd::launch_scan_digit_counts(radix_bits, passes, digit_hist, digit_base, stream));
+        LSD_HIP(lsd::launch_scan_regions(radix_bits, passes, L.regions, counts, (uint32_t)n, (uint32_t)shape->tile(),
+                                         L.region0, tables, stream));
         if (ev) LSD_TRY(ev->mark());
     } else if (ev) {
         LSD_TRY(ev->mark());
@@ -271,11 +290,16 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
         p.xcd_chunk = g_xcd_chunk.load(std::memory_order_relaxed);
         p.stats = g_stats.load(std::memory_order_relaxed);
         if (algorithm == LSDSORT_ALGO_ONESWEEP) {
-            p.digit_base = digit_base + (size_t)pass * bins;
+            p.num_tiles = L.rows;
+            p.regions = tables + (size_t)pass * table_words;
             p.status = reinterpret_cast<uint32_t*>(ws + L.status);
-            p.tile_counter = control + kControlCounterWord + pass;
-            p.chunk_counters = reinterpret_cast<uint32_t*>(ws + L.chunk_counters) + (size_t)pass * L.groups * 8u;
-            p.parity = (uint32_t)(pass & 1);
+            p.tickets = reinterpret_cast<uint32_t*>(ws + L.tickets) + (size_t)pass * lsd::kRegions;
+            // The status rows a pass uses depend on its regions, so a row may sit out a pass; the
+            // parity-coded reuse of lsd_device.hpp needs every word rewritten every pass.  Clear
+            // instead: rows * 2^R words, about 1 % of the pass's traffic.
+            p.parity = 0;
+            if (pass > 0)
+                LSD_HIP(hipMemsetAsync(ws + L.status, 0, (size_t)L.rows * ((size_t)1 << radix_bits) * sizeof(uint32_t), stream));
             LSD_HIP(lsd::launch_rank_scatter(radix_bits, *shape, rank_method, true, p, stream));
         } else {
             uint32_t* tile_hist = reinterpret_cast<uint32_t*>(ws + L.tile_hist);
@@ -341,19 +365,20 @@ int sort_host(uint32_t* keys, uint32_t* vals, size_t n, int radix_bits)
 }
 
 struct MsbLayout {
-    size_t control = 0, hist = 256, status = 512, zero_bytes = 0, base = 0, total = 0;
-    uint32_t tiles = 0;
+    size_t control = 0, tickets = 256, counts = 512, status = 768, zero_bytes = 0, table = 0, total = 0;
+    uint32_t rows = 0;
 };
 
 MsbLayout make_msb_layout(size_t n, int msb_bits)
 {
     MsbLayout L;
-    const TileShape* shape = current_shape(msb_bits ? msb_bits : 1);
+    const int r = msb_bits ? msb_bits : 1;
+    const TileShape* shape = current_shape(r);
     const size_t tile = (size_t)shape->tile();
-    L.tiles = (uint32_t)((n + tile - 1) / tile);
-    L.zero_bytes = align_up(L.status + (size_t)L.tiles * ((size_t)1 << msb_bits) * sizeof(uint32_t));
-    L.base = L.zero_bytes;
-    L.total = L.base + 256;
+    L.rows = (uint32_t)((n + tile - 1) / tile) + (uint32_t)lsd::kRegions;
+    L.zero_bytes = align_up(L.status + (size_t)L.rows * ((size_t)1 << r) * sizeof(uint32_t));
+    L.table = L.zero_bytes;
+    L.total = align_up(L.table + lsd::region_table_words(r) * sizeof(uint32_t));
     return L;
 }
 
@@ -652,8 +677,8 @@ int lsdsort_msb_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size
         return LSDSORT_ERR_WORKSPACE;
     char* ws = static_cast<char*>(d_workspace);
     uint32_t* control = reinterpret_cast<uint32_t*>(ws + L.control);
-    uint32_t* hist = reinterpret_cast<uint32_t*>(ws + L.hist);
-    uint32_t* base = reinterpret_cast<uint32_t*>(ws + L.base);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(ws + L.counts);
+    uint32_t* table = reinterpret_cast<uint32_t*>(ws + L.table);
     const int bins = 1 << msb_bits;
     LSD_HIP(hipMemsetAsync(ws, 0, L.zero_bytes, stream));
     if (msb_bits == 0) {
@@ -664,20 +689,21 @@ int lsdsort_msb_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size
     }
     if (n) {
         const uint32_t shift = (uint32_t)(32 - msb_bits);
+        const TileShape* shape = current_shape(msb_bits);
         LSD_HIP(lsd::launch_digit_histograms(msb_bits, 1, shift, d_in, (uint32_t)n, hist, stream));
-        LSD_HIP(lsd::launch_scan_digit_counts(msb_bits, 1, hist, base, stream));
+        LSD_HIP(lsd::launch_scan_regions(msb_bits, 1, 1, hist, (uint32_t)n, (uint32_t)shape->tile(), 0, table, stream));
         PassParams p{};
         p.in = d_in;
         p.out = d_out;
         p.n = (uint32_t)n;
         p.shift = shift;
-        p.num_tiles = L.tiles;
-        p.digit_base = base;
+        p.num_tiles = L.rows;
+        p.regions = table;
         p.status = reinterpret_cast<uint32_t*>(ws + L.status);
-        p.tile_counter = control + kControlCounterWord;
+        p.tickets = reinterpret_cast<uint32_t*>(ws + L.tickets);
         p.parity = 0;
         p.fault = control;
-        LSD_HIP(lsd::launch_rank_scatter(msb_bits, *current_shape(msb_bits), resolve_rank_method(dev, msb_bits), true, p, stream));
+        LSD_HIP(lsd::launch_rank_scatter(msb_bits, *shape, resolve_rank_method(dev, msb_bits), true, p, stream));
     }
     LSD_HIP(lsd::launch_widen_counts(hist, d_counts, bins, stream));
     return LSDSORT_OK;

@@ -18,6 +18,9 @@ hipError_t launch_rank_scatter_r8(int shape_id, int rank_method, bool chained, c
         case 8: return launch_rank_scatter_shape<8, 1024, 32, 16384>(rank_method, chained, p, stream);
         case 9: return launch_rank_scatter_shape<8, 1024, 32, 8192>(rank_method, chained, p, stream);
         case 10: return launch_rank_scatter_shape<8, 256, 64, 8192>(rank_method, chained, p, stream);
+        case 11: return launch_rank_scatter_shape<8, 512, 24, 4096>(rank_method, chained, p, stream);
+        case 12: return launch_rank_scatter_shape<8, 512, 20, 2048>(rank_method, chained, p, stream);
+        case 13: return launch_rank_scatter_shape<8, 1024, 16, 8192>(rank_method, chained, p, stream);
         default: return hipErrorInvalidValue;
     }
 }

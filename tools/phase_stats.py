@@ -26,12 +26,16 @@ for cfg in a.cfgs:
             lsd.set_xcd_chunk(C)
             ws = lsd.alloc_workspace(n, 8, False, algo)
             k = master.clone(); lsd.GPULSDRadixSort(k, 8, algorithm=algo, workspace=ws); torch.cuda.synchronize()
-            stats.zero_()
+            stats.zero_(); torch.cuda.synchronize()
             k = master.clone()
             tm = lsd.GPULSDRadixSortTimed(k, 8, algorithm=algo, workspace=ws)
             assert tm["tiles"] <= (1 << 17)
             rec = stats.cpu().numpy().astype(np.float64)[: tm["tiles"] * 10].reshape(-1, 10)   # last pass's records
             s = np.zeros(16); s[14] = rec[:, 7].mean(); s[13] = rec[:, 8].mean(); tiles = 1
             per = rec[:, :7].mean(axis=0) / 100.0   # us per tile (100 MHz clock)
+            rr = rec[rec[:, 9] > 0]
+            st = (rr[:, 9] - rr[:, 9].min()) / 100.0; en = st + rr[:, :7].sum(axis=1) / 100.0
+            print("   concurrency at 25/50/75%:", [int(np.sum((st <= q) & (en > q))) for q in (en.max() * 0.25, en.max() * 0.5, en.max() * 0.75)], flush=True)
+            np.save(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', f'rec_cfg{cfg}_algo{algo}.npy'), rec)
             print(f"cfg={cfg} tile={tm['tile_keys']} algo={algo} C={C:2d} scatter/pass={np.mean(tm['scatter_ms']):.3f} ms | " +
                   " ".join(f"{nm}={v:5.2f}" for nm, v in zip(names, per)) + f" | sum={per.sum():5.2f} us/tile refills/tile={s[14]/tiles:.2f} emptypolls/tile={s[13]/tiles:.2f}", flush=True)
