@@ -169,15 +169,20 @@ __global__ void __launch_bounds__(kHistThreads) joint_histograms_kernel(const ui
 {
     constexpr int P = 32 / R;
     constexpr int F = (1 << R) * kRegions;   // fields per pass
-    __shared__ uint32_t s_joint[P * F];
+    // Narrow digits put 64 lanes on 128 words per pass: replicate the table so that neighbouring
+    // lanes use different words (and banks); wide digits spread by themselves.
+    constexpr int C = F >= 1024 ? 1 : 4;
+    __shared__ uint32_t s_joint[P * F * C];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t j = tid; j < (uint32_t)(P * F); j += kHistThreads) s_joint[j] = 0;
+    const uint32_t copy = tid & (C - 1);
+    for (uint32_t j = tid; j < (uint32_t)(P * F * C); j += kHistThreads) s_joint[j] = 0;
     __syncthreads();
 
     auto count_key = [&](uint32_t k, uint32_t region0) {
-        atomicAdd(&s_joint[(digit_at<R>(k, 0) << 3) | region0], 1u);
+        atomicAdd(&s_joint[((digit_at<R>(k, 0) << 3) | region0) * C + copy], 1u);
 #pragma unroll
-        for (int p = 1; p < P; p++) atomicAdd(&s_joint[p * F + digit_at<R + 3>(k, (uint32_t)(R * p - 3))], 1u);
+        for (int p = 1; p < P; p++)
+            atomicAdd(&s_joint[(p * F + digit_at<R + 3>(k, (uint32_t)(R * p - 3))) * C + copy], 1u);
     };
 
     const uint4* __restrict__ keys4 = reinterpret_cast<const uint4*>(keys);
@@ -206,7 +211,9 @@ __global__ void __launch_bounds__(kHistThreads) joint_histograms_kernel(const ui
     }
     __syncthreads();
     for (uint32_t j = tid; j < (uint32_t)(P * F); j += kHistThreads) {
-        const uint32_t c = s_joint[j];
+        uint32_t c = 0;
+#pragma unroll
+        for (int q = 0; q < C; q++) c += s_joint[j * C + q];
         if (c) atomicAdd(&joint[j], c);
     }
 }
@@ -594,9 +601,9 @@ hipError_t launch_rank_scatter_r8(int shape_id, int rank_method, bool chained, c
 hipError_t launch_rank_scatter_r4(int shape_id, int rank_method, bool chained, const PassParams& p, hipStream_t stream);
 hipError_t launch_rank_scatter_small(int radix_bits, int rank_method, bool chained, const PassParams& p, hipStream_t stream);
 
-static const TileShape kShapesR8[] = {{512, 16}, {256, 16}, {1024, 16}, {512, 32}, {1024, 32}, {512, 32}, {512, 64},
-                                      {512, 64}, {1024, 32}, {1024, 32}, {256, 64}, {512, 24}, {512, 20}, {1024, 16}};
-static const TileShape kShapesR4[] = {{512, 16}, {256, 16}};
+// Slot 0 is the default; the others stay compiled for tools/tune.py (DESIGN.md has the sweep).
+static const TileShape kShapesR8[] = {{512, 32}, {1024, 32}, {512, 16}, {256, 16}, {1024, 32}};
+static const TileShape kShapesR4[] = {{512, 32}, {512, 16}, {256, 16}, {1024, 32}};
 static const TileShape kShapesSmall[] = {{256, 16}};
 
 int tile_shapes(int radix_bits, const TileShape** out)

@@ -45,7 +45,7 @@
 namespace lsd {
 
 #ifndef LSD_PERSIST
-#define LSD_PERSIST 1
+#define LSD_PERSIST 0
 #endif
 
 template <int R, int T, int K, int CAP, int RANK>
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
 #endif
     constexpr int LB = LSD_LOOKBACK_WINDOW;   // predecessors inspected per look-back step
 #ifndef LSD_PERSIST
-#define LSD_PERSIST 1
+#define LSD_PERSIST 0
 #endif
     constexpr bool PERSIST = CHAINED && (LSD_PERSIST != 0);   // workgroups loop over tiles, prefetching the next
     static_assert(T % kWave == 0 && H <= T, "one thread per digit in the tile scan");

@@ -7,8 +7,10 @@ namespace lsd {
 hipError_t launch_rank_scatter_r4(int shape_id, int rank_method, bool chained, const PassParams& p, hipStream_t stream)
 {
     switch (shape_id) {
-        case 0: return launch_rank_scatter_shape<4, 512, 16>(rank_method, chained, p, stream);
-        case 1: return launch_rank_scatter_shape<4, 256, 16>(rank_method, chained, p, stream);
+        case 0: return launch_rank_scatter_shape<4, 512, 32, 16384>(rank_method, chained, p, stream);
+        case 1: return launch_rank_scatter_shape<4, 512, 16, 8192>(rank_method, chained, p, stream);
+        case 2: return launch_rank_scatter_shape<4, 256, 16, 4096>(rank_method, chained, p, stream);
+        case 3: return launch_rank_scatter_shape<4, 1024, 32, 16384>(rank_method, chained, p, stream);
         default: return hipErrorInvalidValue;
     }
 }

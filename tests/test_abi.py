@@ -84,7 +84,7 @@ def test_workspace_sizes():
         prev = L.lsdsort_workspace_bytes(n, 8, 0)
     # the reference skips configurations whose tables outgrow the input (.cu:940); ours never do at 1 GiB
     n = 1 << 28
-    assert L.lsdsort_workspace_bytes(n, 8, 0) - 4 * n < 4 * n // 16
+    assert L.lsdsort_workspace_bytes(n, 8, 0) - 4 * n < 4 * n // 8
     assert L.lsdsort_tile_keys(8) > 0 and L.lsdsort_tile_keys(4) > 0 and L.lsdsort_tile_keys(5) == 0
 
 

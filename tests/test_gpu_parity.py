@@ -135,7 +135,7 @@ def test_tile_configs(gpu, oracle_mod):
     vals = np.arange(keys.size, dtype=np.uint32)
     ek, ev = oracle_mod.std_stable_sort_pairs(keys, vals)
     try:
-        for r, count in ((8, 3), (4, 2)):
+        for r, count in ((8, 5), (4, 4)):
             for cfg in range(count):
                 gpu.set_tile_config(r, cfg)
                 for algo in ALGOS.values():
@@ -196,10 +196,12 @@ def test_stage_histograms(gpu, oracle_mod, r, bg):
 def test_stage_histograms_reference_vector(gpu, golden):
     """The reference's own BuildHistogramsCPU output, regrouped to our tile size."""
     keys = golden["hist_in"]                                   # 8192 keys = 8 reference blocks of 1024
-    assert gpu.tile_keys(8) % 1024 == 0
-    per_ref_tile = gpu.tile_keys(8) // 1024
-    ref = golden["hist_block1024_r8_bg1"].astype(np.uint64)
-    ref = ref.reshape(-1, per_ref_tile, 256).sum(axis=1)
+    tile = gpu.tile_keys(8)
+    assert tile % 1024 == 0
+    per_ref_tile = tile // 1024
+    blocks = golden["hist_block1024_r8_bg1"].astype(np.uint64)  # [8][256]
+    tiles = (keys.size + tile - 1) // tile
+    ref = np.stack([blocks[t * per_ref_tile:(t + 1) * per_ref_tile].sum(axis=0) for t in range(tiles)])
     h = gpu.to_host(gpu.BuildHistograms(gpu.to_device(keys), 8, 1).reshape(-1)).reshape(-1, 256)
     assert np.array_equal(h.astype(np.uint64), ref)
 
