@@ -197,8 +197,6 @@ def main():
             clear.append(tm["clear_ms"])
             totals.append(tm["total_ms"])
         per_key = 16 if args.pairs else 8          # one read + one write of the key (and payload) per pass
-        if algo == lsd.LSDSORT_ALGO_STAGED:
-            pass                                    # scatter_ms then includes the pass's histogram and scan kernels
         scat_ms = float(np.mean(scat))
         achieved = per_key * n / (scat_ms * 1e-3) / 1e9
         traffic = None

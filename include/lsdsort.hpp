@@ -1,0 +1,54 @@
+// lsdsort.hpp -- C++ face of liblsdsort.so: namespace lsd { sort(...) }.
+//
+// `lsd::sort(uint32_t* keys, size_t n)` is the host-side entry point BASELINE.json's north_star
+// names.  The reference has no such symbol; it is defined as the body of
+// TestGPULSDRadixSort between LSDRadixSort/LSDRadixSort.cu:1001 and :1005 (H2D, GPULSDRadixSort,
+// D2H).  Header-only wrappers over include/lsdsort.h; a non-zero status becomes an exception (the
+// reference crashes instead: MYCRASH, Utils.h:6-15).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+#include "lsdsort.h"
+
+namespace lsd {
+
+class sort_error : public std::runtime_error {
+public:
+    sort_error(int status, const char* where)
+        : std::runtime_error(std::string(where) + ": " + lsdsort_strerror(status)), status_(status) {}
+    int status() const noexcept { return status_; }
+
+private:
+    int status_;
+};
+
+inline void check(int status, const char* where)
+{
+    if (status != LSDSORT_OK) throw sort_error(status, where);
+}
+
+// Host array, in place, ascending.  Blocking.
+inline void sort(uint32_t* keys, size_t n) { check(lsdsort_u32(keys, n), "lsdsort_u32"); }
+inline void sort(uint32_t* keys, size_t n, int radix_bits) { check(lsdsort_u32_ex(keys, n, radix_bits, 1), "lsdsort_u32_ex"); }
+
+// Host key/value arrays, stable by key.
+inline void sort_pairs(uint32_t* keys, uint32_t* vals, size_t n) { check(lsdsort_pairs_u32(keys, vals, n), "lsdsort_pairs_u32"); }
+
+// Device-resident sort, stream-ordered: the counterpart of GPULSDRadixSort(a, b, h, ...), .cu:839.
+inline size_t workspace_bytes(size_t n, int radix_bits = 8, bool pairs = false) { return lsdsort_workspace_bytes(n, radix_bits, pairs ? 1 : 0); }
+inline void sort_device(uint32_t* d_keys, void* d_workspace, size_t workspace_bytes_, size_t n, int radix_bits = 8,
+                        void* hip_stream = nullptr)
+{
+    check(lsdsort_u32_device(d_keys, d_workspace, workspace_bytes_, n, radix_bits, hip_stream), "lsdsort_u32_device");
+}
+inline void sort_pairs_device(uint32_t* d_keys, uint32_t* d_vals, void* d_workspace, size_t workspace_bytes_, size_t n,
+                              int radix_bits = 8, void* hip_stream = nullptr)
+{
+    check(lsdsort_pairs_u32_device(d_keys, d_vals, d_workspace, workspace_bytes_, n, radix_bits, hip_stream),
+          "lsdsort_pairs_u32_device");
+}
+
+}  // namespace lsd
