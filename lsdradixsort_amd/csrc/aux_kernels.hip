@@ -185,25 +185,38 @@ __global__ void __launch_bounds__(kHistThreads) joint_histograms_kernel(const ui
             atomicAdd(&s_joint[(p * F + digit_at<R + 3>(k, (uint32_t)(R * p - 3))) * C + copy], 1u);
     };
 
+    // Software-pipelined: the next group of 16-byte loads is in flight while the current group's
+    // keys go through the LDS atomics, so the memory pipe and the LDS stay busy together.
     const uint4* __restrict__ keys4 = reinterpret_cast<const uint4*>(keys);
-    for (uint32_t c = blockIdx.x * kHistVecPerThread; c < vec_chunks; c += gridDim.x * kHistVecPerThread) {
-        uint4 v[kHistVecPerThread];
+    auto load_group = [&](uint32_t c, uint4 (&v)[kHistVecPerThread]) {
 #pragma unroll
         for (int u = 0; u < kHistVecPerThread; u++) {
             const uint32_t cc = c + u;
             v[u] = cc < vec_chunks ? keys4[(size_t)cc * kHistThreads + tid] : make_uint4(0, 0, 0, 0);
         }
+    };
+    const uint32_t stride = gridDim.x * kHistVecPerThread;
+    uint32_t c = blockIdx.x * kHistVecPerThread;
+    uint4 cur[kHistVecPerThread];
+    if (c < vec_chunks) load_group(c, cur);
+    while (c < vec_chunks) {
+        uint4 nxt[kHistVecPerThread];
+        const uint32_t cn = c + stride;
+        if (cn < vec_chunks) load_group(cn, nxt);
 #pragma unroll
         for (int u = 0; u < kHistVecPerThread; u++) {
             if (c + u < vec_chunks) {
                 // region0_keys is a multiple of the 1024-key chunk, so the chunk is in one region
                 const uint32_t region0 = ((c + u) * (uint32_t)(kHistThreads * 4)) / region0_keys;
-                count_key(v[u].x, region0);
-                count_key(v[u].y, region0);
-                count_key(v[u].z, region0);
-                count_key(v[u].w, region0);
+                count_key(cur[u].x, region0);
+                count_key(cur[u].y, region0);
+                count_key(cur[u].z, region0);
+                count_key(cur[u].w, region0);
             }
         }
+#pragma unroll
+        for (int u = 0; u < kHistVecPerThread; u++) cur[u] = nxt[u];
+        c = cn;
     }
     if (blockIdx.x == 0) {
         const uint32_t tail_begin = vec_chunks * (kHistThreads * 4);
@@ -602,7 +615,7 @@ hipError_t launch_rank_scatter_r4(int shape_id, int rank_method, bool chained, c
 hipError_t launch_rank_scatter_small(int radix_bits, int rank_method, bool chained, const PassParams& p, hipStream_t stream);
 
 // Slot 0 is the default; the others stay compiled for tools/tune.py (DESIGN.md has the sweep).
-static const TileShape kShapesR8[] = {{512, 32}, {1024, 32}, {512, 16}, {256, 16}, {1024, 32}};
+static const TileShape kShapesR8[] = {{512, 32}, {1024, 32}, {512, 16}, {256, 16}, {1024, 32}, {256, 32}};
 static const TileShape kShapesR4[] = {{512, 32}, {512, 16}, {256, 16}, {1024, 32}};
 static const TileShape kShapesSmall[] = {{256, 16}};
 

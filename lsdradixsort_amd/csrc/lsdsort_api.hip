@@ -56,15 +56,19 @@ size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 bool valid_radix(int r) { return r == 1 || r == 2 || r == 4 || r == 8; }
 
-std::atomic<int> g_shape_id[9];   // per radix_bits, 0 = default
+std::atomic<int> g_shape_override[9];   // per radix_bits: 0 = default, k + 1 = compiled shape k forced
 
-const TileShape* current_shape(int radix_bits)
+// Tile shape of a sort: the compiled default for (radix, keys-only / key-value), unless
+// lsdsort_set_tile_config pinned one.  Key/value tiles carry a payload register per key, so at
+// 8-bit digits their best shape is the one-workgroup-per-CU 1024x32 tile.
+const TileShape* current_shape(int radix_bits, bool pairs = false)
 {
     const TileShape* shapes = nullptr;
     const int count = lsd::tile_shapes(radix_bits, &shapes);
     if (count == 0) return nullptr;
-    int id = g_shape_id[radix_bits].load(std::memory_order_relaxed);
-    if (id < 0 || id >= count) id = 0;
+    int id = g_shape_override[radix_bits].load(std::memory_order_relaxed) - 1;
+    if (id < 0) id = (pairs && radix_bits == 8 && count > 4) ? 4 : 0;
+    if (id >= count) id = 0;
     return &shapes[id];
 }
 
@@ -234,9 +238,9 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     int dev = 0;
     LSD_TRY(check_device_ready(&dev));
     const int rank_method = resolve_rank_method(dev, radix_bits);
-    const TileShape* shape = current_shape(radix_bits);
-    if (!shape) return LSDSORT_ERR_INVALID_ARG;
     const bool pairs = d_vals != nullptr;
+    const TileShape* shape = current_shape(radix_bits, pairs);
+    if (!shape) return LSDSORT_ERR_INVALID_ARG;
     const Layout L = make_layout(n, radix_bits, pairs, algorithm, *shape);
     if (!d_ws || (reinterpret_cast<uintptr_t>(d_ws) & (kAlign - 1)) || ws_bytes < L.total) return LSDSORT_ERR_WORKSPACE;
 
@@ -440,9 +444,8 @@ int lsdsort_set_tile_config(int radix_bits, int config_id)
     const TileShape* shapes = nullptr;
     const int count = lsd::tile_shapes(radix_bits, &shapes);
     if (count == 0) return LSDSORT_ERR_INVALID_ARG;
-    if (config_id < 0) config_id = 0;
     if (config_id >= count) return LSDSORT_ERR_INVALID_ARG;
-    g_shape_id[radix_bits].store(config_id, std::memory_order_relaxed);
+    g_shape_override[radix_bits].store(config_id < 0 ? 0 : config_id + 1, std::memory_order_relaxed);
     return LSDSORT_OK;
 }
 
@@ -491,7 +494,7 @@ size_t lsdsort_workspace_bytes_ex(size_t n, int radix_bits, int pairs, int algor
 {
     if (!valid_radix(radix_bits) || n > LSDSORT_MAX_KEYS) return 0;
     if (algorithm != LSDSORT_ALGO_ONESWEEP && algorithm != LSDSORT_ALGO_STAGED) return 0;
-    const TileShape* shape = current_shape(radix_bits);
+    const TileShape* shape = current_shape(radix_bits, pairs != 0);
     return make_layout(n, radix_bits, pairs != 0, algorithm, *shape).total;
 }
 

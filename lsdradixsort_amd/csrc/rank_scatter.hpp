@@ -44,21 +44,6 @@
 
 namespace lsd {
 
-#ifndef LSD_PERSIST
-#define LSD_PERSIST 0
-#endif
-
-template <int R, int T, int K, int CAP, int RANK>
-constexpr int rank_scatter_lds_words()
-{
-    constexpr int H = 1 << R;
-    constexpr int W = T / kWave;
-    constexpr int keys_words = CAP;
-    constexpr int tab_words = RANK == kRankLdsOr ? W * H * 2 : 0;
-    constexpr int buf = keys_words > tab_words ? keys_words : tab_words;
-    return buf + W * H + H + 32;
-}
-
 // LDS-only workgroup barrier: waits for this wave's LDS traffic, not for its global loads, so
 // look-back loads issued before it stay in flight across it.
 __device__ __forceinline__ void lds_barrier()
@@ -92,7 +77,29 @@ __device__ __forceinline__ void lds_barrier()
 template <int T, int K>
 constexpr int min_waves_per_simd()
 {
-    return K <= 16 ? (T <= 512 ? 7 : 8) : (K <= 24 ? (T <= 512 ? 6 : 4) : (K <= 32 ? 4 : 2));
+    return K <= 16 ? (T <= 512 ? 7 : 8) : (K <= 32 ? 4 : 2);
+}
+
+// Look-back geometry: LB status rows per thread per step; the first step is taken by up to four
+// "slots" of threads at once (thread t: digit t % H, slot t / H), so it covers SLOTS*LB predecessors
+// with one round trip.
+template <int R, int T>
+struct Lookback {
+    static constexpr int H = 1 << R;
+    static constexpr int LB = H >= 64 ? 4 : 8;
+    static constexpr int SLOTS = 1;   // measured: helper slots (2 or 4) buy nothing here, the extra barrier costs a little
+    static constexpr int LDS_WORDS = (SLOTS - 1) * LB * H;
+};
+
+template <int R, int T, int K, int CAP, int RANK>
+constexpr int rank_scatter_lds_words()
+{
+    constexpr int H = 1 << R;
+    constexpr int W = T / kWave;
+    constexpr int keys_words = CAP;
+    constexpr int tab_words = RANK == kRankLdsOr ? W * H * 2 : 0;
+    constexpr int buf = keys_words > tab_words ? keys_words : tab_words;
+    return buf + W * H + H + 32 + Lookback<R, T>::LDS_WORDS;
 }
 
 template <int R, int T, int K, int CAP, int RANK, bool PAIRS, bool CHAINED>
@@ -110,14 +117,8 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     constexpr int KEYS_WORDS = CAP;
     constexpr int TAB_WORDS = RANK == kRankLdsOr ? W * H * 2 : 0;
     constexpr int BUF_WORDS = KEYS_WORDS > TAB_WORDS ? KEYS_WORDS : TAB_WORDS;
-#ifndef LSD_LOOKBACK_WINDOW
-#define LSD_LOOKBACK_WINDOW (H >= 64 ? 4 : 8)
-#endif
-    constexpr int LB = LSD_LOOKBACK_WINDOW;   // predecessors inspected per look-back step
-#ifndef LSD_PERSIST
-#define LSD_PERSIST 0
-#endif
-    constexpr bool PERSIST = CHAINED && (LSD_PERSIST != 0);   // workgroups loop over tiles, prefetching the next
+    constexpr int LB = Lookback<R, T>::LB;          // status rows per thread per look-back step
+    constexpr int LSLOTS = Lookback<R, T>::SLOTS;   // thread slots sharing the first step
     static_assert(T % kWave == 0 && H <= T, "one thread per digit in the tile scan");
     static_assert(TILE % CAP == 0 && CAP % T == 0 && (CAP & (CAP - 1)) == 0, "rounds must tile the tile");
 
@@ -129,75 +130,69 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     volatile lds_u64* const s_tab = (volatile lds_u64*)smem;          // [W][H]   (phase 2, kRankLdsOr, overlays s_keys)
     volatile lds_u32* const s_cnt = (volatile lds_u32*)(s_base + BUF_WORDS);  // [W][H] counters, then wave bases
     lds_u32* const s_gdelta = s_base + BUF_WORDS + W * H;             // [H] global base - local offset
-    lds_u32* const s_misc = s_gdelta + H;                             // [1..17] wave totals, [28..29] claimed tile
+    lds_u32* const s_misc = s_gdelta + H;                             // [1..17] wave totals, [24..29] claimed tile
+    lds_u32* const s_look = s_misc + 32;                              // [LSLOTS-1][LB][H] first-step status rows
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
     const uint32_t shift = p.shift;
 
-    // ---- tile acquisition --------------------------------------------------------------------
-    // Chained form: the workgroup is persistent and takes tiles from ticket dispensers, one per
-    // region.  A tile only ever waits on earlier tickets of the SAME dispenser, i.e. on tiles some
-    // workgroup has already taken (as its current tile, or as the one it will start right after its
-    // current, lower-numbered one): the lowest unfinished tile is always somebody's current tile,
-    // so the look-back cannot deadlock whatever the dispatch order, placement or residency (the
-    // MI355X guide: never assume any of them).  A workgroup serves the region of its own XCD first
-    // (hardware XCC_ID) and the others when that one is used up: placement is for speed only
-    // (neighbouring runs meet in one L2; each XCD walks its own short chain).
-    auto claim = [&]() {   // thread 0: take the next ticket, leave (region, ticket) in LDS
-        uint32_t xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        uint32_t got = 0xFFFFFFFFu, ticket = 0;
-        for (uint32_t a = 0; a < (uint32_t)kRegions; a++) {
-            const uint32_t x = (xcc + a) & (uint32_t)(kRegions - 1);
-            const uint32_t region_tiles = p.regions[16 + x];
-            if (region_tiles == 0) continue;
-            ticket = atomicAdd(p.tickets + x, 1u);
-            if (ticket < region_tiles) {
-                got = x;
-                break;
-            }
+    // wave-private tables start at zero
+#pragma unroll
+    for (int j = 0; j < (H + kWave - 1) / kWave; j++) {
+        const uint32_t d = j * kWave + lane;
+        if (H >= kWave || d < H) {
+            s_cnt[wave * H + d] = 0;
+            if (RANK == kRankLdsOr) s_tab[wave * H + d] = 0;
         }
-        s_misc[28] = got;
-        s_misc[29] = ticket;
-    };
+    }
 
-    uint32_t tile = 0;        // row of the tile in the status array
-    uint32_t chain_pos = 0;   // its position in its region's chain
-    uint32_t tile_base = 0;   // index of its first key
-    uint32_t range_end = 0;   // one past the last key it may touch
+    uint32_t tile;             // row of this tile in the status array
+    uint32_t chain_pos = 0;    // position in its region's chain (chained form)
+    uint32_t tile_base;        // index of the tile's first key
+    uint32_t range_end;        // one past the last key this tile may touch
     uint32_t region = 0;
     uint32_t chain_row0 = 0;
-    auto adopt = [&]() -> bool {   // all threads, after a barrier that follows claim()
+    if (CHAINED) {
+        // A tile comes from a ticket taken on arrival from its region's dispenser, and it only ever
+        // waits on earlier tickets of the SAME dispenser -- workgroups that have already started.
+        // So the look-back cannot deadlock whatever the dispatch order, placement or residency (the
+        // MI355X guide: never assume any of them).  A workgroup serves the region of its own XCD
+        // first (hardware XCC_ID) and moves on to the others when that one is used up: placement is
+        // for speed only (neighbouring runs meet in one L2; each XCD walks its own short chain).
+        if (tid == 0) {
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            uint32_t got = 0xFFFFFFFFu;
+            for (uint32_t a = 0; a < (uint32_t)kRegions; a++) {
+                const uint32_t x = (xcc + a) & (uint32_t)(kRegions - 1);
+                // ticket and region extents in ONE round trip: the ticket is taken before the tile
+                // count is known (an over-run ticket of an exhausted or empty region is harmless)
+                const uint32_t ticket = atomicAdd(p.tickets + x, 1u);
+                const uint32_t region_tiles = p.regions[16 + x];
+                const uint32_t r_start = p.regions[x], r_len = p.regions[8 + x], row0 = p.regions[24 + x];
+                if (ticket < region_tiles) {
+                    got = x;
+                    s_misc[24] = r_start;
+                    s_misc[25] = r_len;
+                    s_misc[26] = row0;
+                    s_misc[29] = ticket;
+                    break;
+                }
+            }
+            s_misc[28] = got;
+        }
+        __syncthreads();
         region = __builtin_amdgcn_readfirstlane(s_misc[28]);
-        if (region == 0xFFFFFFFFu) return false;
+        if (region == 0xFFFFFFFFu) return;   // uniform: the grid is an upper bound on the tile count
         chain_pos = __builtin_amdgcn_readfirstlane(s_misc[29]);
-        const uint32_t r_start = p.regions[region];
-        chain_row0 = p.regions[24 + region];
+        const uint32_t r_start = __builtin_amdgcn_readfirstlane(s_misc[24]);
+        const uint32_t r_len = __builtin_amdgcn_readfirstlane(s_misc[25]);
+        chain_row0 = __builtin_amdgcn_readfirstlane(s_misc[26]);
         tile = chain_row0 + chain_pos;
         tile_base = r_start + chain_pos * (uint32_t)TILE;
-        range_end = r_start + p.regions[8 + region];
-        return true;
-    };
-
-    if (CHAINED) {
-#ifdef LSD_STAGGER
-        // de-synchronise the persistent workgroups of an XCD: a one-off delay spread over roughly
-        // one tile period, so that tiles of one chain reach their look-back one after another
-        if (PERSIST) {
-            const uint32_t slot = (blockIdx.x >> 3) & 127u;
-            for (uint32_t z = 0; z < slot * (uint32_t)LSD_STAGGER; z++) __builtin_amdgcn_s_sleep(16);
-        }
-#endif
-        if (tid == 0) claim();
-        __syncthreads();
-        if (!adopt()) return;   // uniform: nothing left for this workgroup
-#ifdef LSD_PHASE_STATS
-        stat_row__ = tile;
-        if (tid == 0 && p.stats) p.stats[(size_t)stat_row__ * 10 + 9] = stamp__;
-#endif
-        LSD_STAMP(0);   // ticket
+        range_end = r_start + r_len;
     } else {
         tile = blockIdx.x;
         // Affinity for the table-driven form, where tiles are independent: blocks with equal
@@ -215,227 +210,235 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         tile_base = tile * (uint32_t)TILE;
         range_end = p.n;
     }
+#ifdef LSD_PHASE_STATS
+    stat_row__ = tile;
+    if (tid == 0 && p.stats) p.stats[(size_t)stat_row__ * 10 + 9] = stamp__;
+    LSD_STAMP(0);   // ticket
+#endif
 
-    // ---- 1. load: wave-striped, so (register row, lane) order == key order --------------------
+    const uint32_t remaining = range_end - tile_base;
+    const uint32_t valid = remaining < (uint32_t)TILE ? remaining : (uint32_t)TILE;
+    const bool full = valid == (uint32_t)TILE;
+
+    // ---- 1. load: wave-striped, so (register row, lane) order == key order ------------------------
     uint32_t key[K];
-    auto load_keys = [&]() {
-        const uint32_t first = tile_base + wave * (uint32_t)(kWave * K) + lane;
-        if (range_end - tile_base >= (uint32_t)TILE) {
+    const uint32_t first = tile_base + wave * (uint32_t)(kWave * K) + lane;
+    if (full) {
 #pragma unroll
-            for (int i = 0; i < K; i++) key[i] = p.in[first + i * kWave];
+        for (int i = 0; i < K; i++) key[i] = p.in[first + i * kWave];
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const uint32_t idx = first + i * kWave;
+            key[i] = idx < range_end ? p.in[idx] : 0xFFFFFFFFu;
+        }
+    }
+
+    // ---- 2. intra-wave stable rank ----------------------------------------------------------
+#ifdef LSD_PHASE_STATS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LSD_STAMP(1);   // key load
+#endif
+    uint32_t rank[K];
+    if (RANK == kRankLdsAdd) {
+        // The returned old value is (same-digit keys in earlier rows) + (peers in lower lanes):
+        // the K atomics are independent, so they issue back to back.
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const uint32_t d = digit_at<R>(key[i], shift);
+            rank[i] = __hip_atomic_fetch_add((lds_u32*)&s_cnt[wave * H + d], 1u, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    } else {
+        const uint64_t lane_bit = 1ull << lane;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const uint32_t d = digit_at<R>(key[i], shift);
+            uint64_t peers;
+            if (RANK == kRankLdsOr) {
+                __hip_atomic_fetch_or((lds_u64*)&s_tab[wave * H + d], lane_bit, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WAVEFRONT);
+                peers = s_tab[wave * H + d];
+            } else {
+                peers = match_ballot<R>(d);
+            }
+            const uint32_t before = s_cnt[wave * H + d];
+            const uint32_t r = mbcnt_add(peers, before);
+            rank[i] = r;
+            if (r == before) {   // lowest peer
+                s_cnt[wave * H + d] = popc64_add(peers, before);
+                if (RANK == kRankLdsOr) s_tab[wave * H + d] = 0;
+            }
+        }
+    }
+    __syncthreads();
+    LSD_STAMP(2);   // rank + barrier
+
+    // ---- 3. per-wave bases, tile digit totals, local offsets -------------------------------
+    uint32_t total = 0;
+    uint32_t wave_excl[W];
+    if (tid < (uint32_t)H) {
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            wave_excl[w] = total;
+            total += s_cnt[w * H + tid];
+        }
+    }
+    // digit totals that other tiles may see: the tail's padding is not data
+    uint32_t pub_total = total;
+    if (tid == (uint32_t)(H - 1)) pub_total -= (uint32_t)TILE - valid;
+
+    const uint32_t parity = p.parity;
+    const uint32_t c_stale = code_stale(parity);
+    const uint32_t c_prefix = code_prefix(parity);
+    // this thread's (digit, slot) column of its region's chain
+    const uint32_t my_digit = tid % (uint32_t)H;
+    const uint32_t my_slot = tid / (uint32_t)H;
+    const uint32_t* const status_col = CHAINED ? p.status + (size_t)chain_row0 * H + my_digit : nullptr;
+    uint32_t window[LB];
+    int32_t j = (int32_t)chain_pos - 1;   // nearest predecessor in the chain not yet consumed
+    if (CHAINED && tid < (uint32_t)H) {
+        // publish as early as possible: successors can already add this tile's counts
+        const uint32_t code = chain_pos == 0 ? c_prefix : code_aggregate(parity);
+        store_status(p.status + (size_t)tile * H + tid, (pub_total << 2) | code);
+    }
+    if (CHAINED && my_slot < (uint32_t)LSLOTS) {
+        // first look-back step, issued now and consumed after the LDS reorder below: slot s covers
+        // predecessors j - s*LB - l, so LSLOTS*LB status rows cost one round trip
+        const int32_t j0 = j - (int32_t)(my_slot * LB);
+#pragma unroll
+        for (int l = 0; l < LB; l++) window[l] = (j0 - l >= 0) ? load_status(status_col + (size_t)(j0 - l) * H) : c_stale;
+    }
+
+    uint32_t incl = wave_inclusive_scan(tid < (uint32_t)H ? total : 0u, lane);
+    if (H > kWave) {
+        if (lane == 63u) s_misc[1 + wave] = incl;
+        lds_barrier();
+        uint32_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < H / kWave; w++)
+            if ((uint32_t)w < wave) carry += s_misc[1 + w];
+        incl += carry;
+    }
+    const uint32_t local_off = incl - total;   // exclusive scan over digits
+    if (tid < (uint32_t)H) {
+#pragma unroll
+        for (int w = 0; w < W; w++) s_cnt[w * H + tid] = local_off + wave_excl[w];
+    }
+    lds_barrier();
+    LSD_STAMP(3);   // totals, publish, scan, bases
+
+    // payload loads go out now; they land while the keys are reordered
+    uint32_t val[PAIRS ? K : 1];
+    if (PAIRS) {
+        if (full) {
+#pragma unroll
+            for (int i = 0; i < K; i++) val[i] = p.vals_in[first + i * kWave];
         } else {
 #pragma unroll
             for (int i = 0; i < K; i++) {
                 const uint32_t idx = first + i * kWave;
-                key[i] = idx < range_end ? p.in[idx] : 0xFFFFFFFFu;
+                val[i] = idx < range_end ? p.vals_in[idx] : 0u;
             }
         }
-    };
-    load_keys();
+    }
 
-    for (;;) {
-        const uint32_t remaining = range_end - tile_base;
-        const uint32_t valid = remaining < (uint32_t)TILE ? remaining : (uint32_t)TILE;
-        const bool full = valid == (uint32_t)TILE;
-        const uint32_t first = tile_base + wave * (uint32_t)(kWave * K) + lane;
-        const uint32_t cur_tile = tile, cur_chain_pos = chain_pos, cur_region = region, cur_end = range_end;
-        // this thread's digit column of its region's chain
-        const uint32_t* const status_col = CHAINED ? p.status + (size_t)chain_row0 * H + tid : nullptr;
-#ifdef LSD_PHASE_STATS
-        stat_row__ = cur_tile;
-        if (!CHAINED && tid == 0 && p.stats) p.stats[(size_t)stat_row__ * 10 + 9] = stamp__;
-#endif
+    // ---- 5. reorder through LDS in ROUNDS rounds of CAP tile positions each ------------------
+    // A key whose tile-sorted position is q belongs to round q / CAP, slot q % CAP.  Rounds are
+    // by position, not by digit, so their size never depends on the key distribution; the tile
+    // (and with it the length of every digit's run in global memory) can exceed the LDS buffer.
+    uint32_t pos[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        // recompute the digit here: carrying K digits (or LDS addresses) over from the rank phase
+        // would cost K registers
+        uint32_t kk = key[i];
+        asm volatile("" : "+v"(kk));
+        const uint32_t d = digit_at<R>(kk, shift);
+        pos[i] = s_cnt[wave * H + d] + rank[i];
+    }
 
-        // wave-private tables start at zero (the previous tile's users are behind a barrier)
 #pragma unroll
-        for (int j = 0; j < (H + kWave - 1) / kWave; j++) {
-            const uint32_t d = j * kWave + lane;
-            if (H >= kWave || d < H) {
-                s_cnt[wave * H + d] = 0;
-                if (RANK == kRankLdsOr) s_tab[wave * H + d] = 0;
-            }
-        }
-
-        // ---- 2. intra-wave stable rank ------------------------------------------------------
-#ifdef LSD_PHASE_STATS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        LSD_STAMP(1);   // key load
-#endif
-        uint32_t rank[K];
-        if (RANK == kRankLdsAdd) {
-            // The returned old value is (same-digit keys in earlier rows) + (peers in lower
-            // lanes): the K atomics are independent, so they issue back to back.
-#pragma unroll
-            for (int i = 0; i < K; i++) {
-                const uint32_t d = digit_at<R>(key[i], shift);
-                rank[i] = __hip_atomic_fetch_add((lds_u32*)&s_cnt[wave * H + d], 1u, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-        } else {
-            const uint64_t lane_bit = 1ull << lane;
-#pragma unroll
-            for (int i = 0; i < K; i++) {
-                const uint32_t d = digit_at<R>(key[i], shift);
-                uint64_t peers;
-                if (RANK == kRankLdsOr) {
-                    __hip_atomic_fetch_or((lds_u64*)&s_tab[wave * H + d], lane_bit, __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    peers = s_tab[wave * H + d];
-                } else {
-                    peers = match_ballot<R>(d);
-                }
-                const uint32_t before = s_cnt[wave * H + d];
-                const uint32_t r = mbcnt_add(peers, before);
-                rank[i] = r;
-                if (r == before) {   // lowest peer
-                    s_cnt[wave * H + d] = popc64_add(peers, before);
-                    if (RANK == kRankLdsOr) s_tab[wave * H + d] = 0;
-                }
-            }
-        }
-        __syncthreads();
-        LSD_STAMP(2);   // rank + barrier
-
-        // ---- 3. per-wave bases, tile digit totals, local offsets ---------------------------
-        uint32_t total = 0;
-        uint32_t wave_excl[W];
-        if (tid < (uint32_t)H) {
-#pragma unroll
-            for (int w = 0; w < W; w++) {
-                wave_excl[w] = total;
-                total += s_cnt[w * H + tid];
-            }
-        }
-        // digit totals that other tiles may see: the tail's padding is not data
-        uint32_t pub_total = total;
-        if (tid == (uint32_t)(H - 1)) pub_total -= (uint32_t)TILE - valid;
-
-        const uint32_t parity = p.parity;
-        const uint32_t c_stale = code_stale(parity);
-        const uint32_t c_prefix = code_prefix(parity);
-        uint32_t window[LB];
-        int32_t j = (int32_t)cur_chain_pos - 1;   // nearest predecessor in the chain not yet consumed
-        if (CHAINED && tid < (uint32_t)H) {
-            // publish as early as possible: successors can already add this tile's counts
-            const uint32_t code = cur_chain_pos == 0 ? c_prefix : code_aggregate(parity);
-            store_status(p.status + (size_t)cur_tile * H + tid, (pub_total << 2) | code);
-            // first look-back window: issued now, consumed after the LDS reorder below
-#pragma unroll
-            for (int l = 0; l < LB; l++)
-                window[l] = (j - l >= 0) ? load_status(status_col + (size_t)(j - l) * H) : c_stale;
-        }
-
-        uint32_t incl = wave_inclusive_scan(tid < (uint32_t)H ? total : 0u, lane);
-        if (H > kWave) {
-            if (lane == 63u) s_misc[1 + wave] = incl;
-            lds_barrier();
-            uint32_t carry = 0;
-#pragma unroll
-            for (int w = 0; w < H / kWave; w++)
-                if ((uint32_t)w < wave) carry += s_misc[1 + w];
-            incl += carry;
-        }
-        const uint32_t local_off = incl - total;   // exclusive scan over digits
-        if (tid < (uint32_t)H) {
-#pragma unroll
-            for (int w = 0; w < W; w++) s_cnt[w * H + tid] = local_off + wave_excl[w];
-        }
-        lds_barrier();
-        LSD_STAMP(3);   // totals, publish, scan, bases
-
-        // payload loads go out now; they land while the keys are reordered
-        uint32_t val[PAIRS ? K : 1];
-        if (PAIRS) {
-            if (full) {
-#pragma unroll
-                for (int i = 0; i < K; i++) val[i] = p.vals_in[first + i * kWave];
-            } else {
-#pragma unroll
-                for (int i = 0; i < K; i++) {
-                    const uint32_t idx = first + i * kWave;
-                    val[i] = idx < cur_end ? p.vals_in[idx] : 0u;
-                }
-            }
-        }
-
-        // ---- 5. reorder through LDS in ROUNDS rounds of CAP tile positions each --------------
-        // A key whose tile-sorted position is q belongs to round q / CAP, slot q % CAP.  Rounds are
-        // by position, not by digit, so their size never depends on the key distribution; the tile
-        // (and with it the length of every digit's run in global memory) can exceed the LDS buffer.
-        uint32_t pos[K];
+    for (int round = 0; round < ROUNDS; round++) {
+        if (round > 0) lds_barrier();   // the previous round has been read back
 #pragma unroll
         for (int i = 0; i < K; i++) {
-            const uint32_t d = digit_at<R>(key[i], shift);
-            pos[i] = s_cnt[wave * H + d] + rank[i];
+            if (ROUNDS == 1 || (pos[i] / (uint32_t)CAP) == (uint32_t)round) s_keys[pos[i] % (uint32_t)CAP] = key[i];
         }
 
-        bool more = false;   // another tile has been claimed for this workgroup
+        if (round == 0) {
+            LSD_STAMP(4);   // first round's LDS writes
+            // ---- 4. tile base per digit ("global offsets", .cu:885-894) ----------------------------
+            if (CHAINED && LSLOTS > 1) {
+                // the helper slots hand their share of the first step to the digit's owner
+                if (my_slot >= 1 && my_slot < (uint32_t)LSLOTS) {
 #pragma unroll
-        for (int round = 0; round < ROUNDS; round++) {
-            if (round > 0) lds_barrier();   // the previous round has been read back
-#pragma unroll
-            for (int i = 0; i < K; i++) {
-                if (ROUNDS == 1 || (pos[i] / (uint32_t)CAP) == (uint32_t)round) s_keys[pos[i] % (uint32_t)CAP] = key[i];
-            }
-            // With the last round written the key registers are free: take the next ticket now, so
-            // its latency and the next tile's loads hide behind this tile's look-back and stores.
-            if (PERSIST && !PAIRS && round == ROUNDS - 1 && tid == 0) claim();
-
-            if (round == 0) {
-                LSD_STAMP(4);   // first round's LDS writes
-                // ---- 4. tile base per digit (overlapped with the first round's LDS writes) --------
-                if (tid < (uint32_t)H) {
-                    uint32_t gbase;
-                    if (CHAINED) {
-                        uint32_t excl = 0;
-                        if (cur_chain_pos > 0) {
-                            uint32_t spins = 0;
-                            for (;;) {
-                                int consumed = 0;
-                                bool found = false;
-#pragma unroll
-                                for (int l = 0; l < LB; l++) {
-                                    const uint32_t code = window[l] & 3u;
-                                    if (!found && consumed == l && code != c_stale) {
-                                        excl += window[l] >> 2;
-                                        consumed = l + 1;
-                                        found = (code == c_prefix) || (j - l == 0);
-                                    }
-                                }
-                                if (found) break;
-                                if (consumed == 0) {
-                                    if (++spins > kSpinLimit) {
-                                        atomicOr(p.fault, 1u);
-                                        break;
-                                    }
-                                    __builtin_amdgcn_s_sleep(1);
-                                    if (tid == 0) LSD_COUNT(8, 1);
-                                }
-                                if (tid == 0) LSD_COUNT(7, 1);
-                                j -= consumed;
-#pragma unroll
-                                for (int l = 0; l < LB; l++)
-                                    window[l] = (j - l >= 0) ? load_status(status_col + (size_t)(j - l) * H) : c_stale;
-                            }
-                            store_status(p.status + (size_t)cur_tile * H + tid, ((excl + pub_total) << 2) | c_prefix);
-                        }
-                        gbase = p.regions[kRegionHeaderWords + cur_region * H + tid] + excl;
-                    } else {
-                        gbase = p.global_off[(size_t)cur_tile * H + tid];
-                    }
-                    s_gdelta[tid] = gbase - local_off;
+                    for (int l = 0; l < LB; l++) s_look[((my_slot - 1) * LB + l) * H + my_digit] = window[l];
                 }
+                lds_barrier();
             }
-            lds_barrier();
-            if (round == 0) LSD_STAMP(5);   // look-back (wave 0's digits) + barrier
-            if (PERSIST && !PAIRS && round == ROUNDS - 1) {
-                more = adopt();
-                if (more) load_keys();   // next tile's keys stream in under the stores below
+            if (tid < (uint32_t)H) {
+                uint32_t gbase;
+                if (CHAINED) {
+                    uint32_t excl = 0;
+                    if (chain_pos > 0) {
+                        // first step: own window, then the helper slots' rows, in chain order
+                        int consumed = 0;
+                        bool found = false;
+#pragma unroll
+                        for (int m = 0; m < LSLOTS * LB; m++) {
+                            const uint32_t word = m < LB ? window[m] : s_look[(m - LB) * H + tid];
+                            const uint32_t code = word & 3u;
+                            if (!found && consumed == m && code != c_stale) {
+                                excl += word >> 2;
+                                consumed = m + 1;
+                                found = (code == c_prefix) || (j - m == 0);
+                            }
+                        }
+                        j -= consumed;
+                        uint32_t spins = 0;
+                        while (!found) {
+                            // further steps: LB rows at a time by the owner alone
+#pragma unroll
+                            for (int l = 0; l < LB; l++)
+                                window[l] = (j - l >= 0) ? load_status(status_col + (size_t)(j - l) * H) : c_stale;
+                            consumed = 0;
+#pragma unroll
+                            for (int l = 0; l < LB; l++) {
+                                const uint32_t code = window[l] & 3u;
+                                if (!found && consumed == l && code != c_stale) {
+                                    excl += window[l] >> 2;
+                                    consumed = l + 1;
+                                    found = (code == c_prefix) || (j - l == 0);
+                                }
+                            }
+                            if (tid == 0) LSD_COUNT(7, 1);
+                            if (consumed == 0) {
+                                if (++spins > kSpinLimit) {
+                                    atomicOr(p.fault, 1u);
+                                    break;
+                                }
+                                __builtin_amdgcn_s_sleep(1);
+                                if (tid == 0) LSD_COUNT(8, 1);
+                            }
+                            j -= consumed;
+                        }
+                        store_status(p.status + (size_t)tile * H + tid, ((excl + pub_total) << 2) | c_prefix);
+                    }
+                    gbase = p.regions[kRegionHeaderWords + region * H + tid] + excl;
+                } else {
+                    gbase = p.global_off[(size_t)tile * H + tid];
+                }
+                s_gdelta[tid] = gbase - local_off;
             }
+        }
+        lds_barrier();
+        if (round == 0) LSD_STAMP(5);   // look-back (wave 0's digits) + barrier
 
-            // linear read-back: consecutive threads hold consecutive tile positions, so each digit's
-            // keys leave as one contiguous run
-            uint32_t dst[SLOTS];
+        // linear read-back: consecutive threads hold consecutive tile positions, so each digit's
+        // keys leave as one contiguous run
+        uint32_t dst[PAIRS ? SLOTS : 1];
+        if (PAIRS) {
 #pragma unroll
             for (int s2 = 0; s2 < SLOTS; s2++) {
                 const uint32_t slot = s2 * T + tid;
@@ -445,39 +448,42 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                 dst[s2] = s_gdelta[d] + q;
                 if (full || q < valid) p.out[dst[s2]] = k;
             }
-
-            // ---- 6. payloads follow their keys through the same slots -------------------------
-            if (PAIRS) {
-                lds_barrier();   // every key of this round has been read back
+        } else {
+            // keys only: sixteen slots at a time, which bounds the registers of the read-back
+            constexpr int STEP = SLOTS < 16 ? SLOTS : 16;
+#pragma unroll 1
+            for (int s0 = 0; s0 < SLOTS; s0 += STEP) {
 #pragma unroll
-                for (int i = 0; i < K; i++) {
-                    if (ROUNDS == 1 || (pos[i] / (uint32_t)CAP) == (uint32_t)round) s_keys[pos[i] % (uint32_t)CAP] = val[i];
-                }
-                lds_barrier();
-#pragma unroll
-                for (int s2 = 0; s2 < SLOTS; s2++) {
-                    const uint32_t slot = s2 * T + tid;
+                for (int u = 0; u < STEP; u++) {
+                    const uint32_t slot = (s0 + u) * T + tid;
                     const uint32_t q = round * CAP + slot;
-                    if (full || q < valid) p.vals_out[dst[s2]] = s_keys[slot];
+                    const uint32_t k = s_keys[slot];
+                    const uint32_t d = digit_at<R>(k, shift);
+                    if (full || q < valid) p.out[s_gdelta[d] + q] = k;
                 }
             }
         }
-#ifdef LSD_PHASE_STATS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        LSD_STAMP(6);   // read-back + stores drained
-        if (tid == 0 && p.stats && more) p.stats[(size_t)tile * 10 + 9] = stamp__;   // next tile's start
-#endif
-        if (!PERSIST) break;
+
+        // ---- 6. payloads follow their keys through the same slots -----------------------------
         if (PAIRS) {
-            // key/value tiles take their next ticket here (the payload registers stay live to the end)
-            if (tid == 0) claim();
+            lds_barrier();   // every key of this round has been read back
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                if (ROUNDS == 1 || (pos[i] / (uint32_t)CAP) == (uint32_t)round) s_keys[pos[i] % (uint32_t)CAP] = val[i];
+            }
             lds_barrier();
-            more = adopt();
-            if (more) load_keys();
+#pragma unroll
+            for (int s2 = 0; s2 < SLOTS; s2++) {
+                const uint32_t slot = s2 * T + tid;
+                const uint32_t q = round * CAP + slot;
+                if (full || q < valid) p.vals_out[dst[s2]] = s_keys[slot];
+            }
         }
-        if (!more) break;
-        lds_barrier();   // nobody still reads this tile's LDS when the next one starts writing it
     }
+#ifdef LSD_PHASE_STATS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LSD_STAMP(6);   // read-back + stores drained
+#endif
 }
 
 // Launch one instantiation.  LDS above 64 KiB needs the attribute raised once per function.
@@ -503,20 +509,7 @@ hipError_t launch_rank_scatter_inst(const PassParams& p, hipStream_t stream)
         }
     }
 #endif
-    uint32_t grid = p.num_tiles;
-    if (CHAINED && (LSD_PERSIST != 0)) {
-        // persistent workgroups: as many as the device holds at once, never more than there are tiles
-        static int resident = 0;
-        if (resident == 0) {
-            int per_cu = 0, dev = 0, cus = 0;
-            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), T, lds_bytes);
-            if (e == hipSuccess) e = hipGetDevice(&dev);
-            if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            if (e != hipSuccess) return e;
-            resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
-        }
-        if (grid > (uint32_t)resident) grid = (uint32_t)resident;
-    }
+    const uint32_t grid = p.num_tiles;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(T), lds_bytes, stream, p);
     return hipGetLastError();
 }

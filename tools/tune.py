@@ -22,7 +22,7 @@ args = ap.parse_args()
 n = 1 << args.log2_keys
 master = lsd.to_device(mt19937_keys(n, 0) & np.uint32(args.mask))
 vals0 = torch.arange(n, dtype=torch.int32, device="cuda") if args.pairs else None
-counts = {8: 5, 4: 4}
+counts = {8: 6, 4: 4}
 for r in args.radix:
     for cfg in (args.cfgs if args.cfgs is not None else range(counts[r])):
         lsd.set_tile_config(r, cfg)
