@@ -178,11 +178,39 @@ __global__ void __launch_bounds__(kHistThreads) joint_histograms_kernel(const ui
     for (uint32_t j = tid; j < (uint32_t)(P * F * C); j += kHistThreads) s_joint[j] = 0;
     __syncthreads();
 
-    auto count_key = [&](uint32_t k, uint32_t region0) {
+    // Low-entropy fields (constant or sorted input, dead high digits) would serialise all 64 lanes
+    // of a wave on one LDS word; when the whole wave agrees on a field, one lane adds 64 instead.
+    // The agreement test is only paid by groups of keys whose FIRST key already shows it in some
+    // field (uniform random input takes the plain path with one test per 16 keys).
+    auto add_field_checked = [&](uint32_t slot) {
+        const uint32_t s0 = __builtin_amdgcn_readfirstlane(slot);
+        if (__builtin_amdgcn_read_exec() == ~0ull && __all(slot == s0)) {
+            if ((tid & 63u) == 0) atomicAdd(&s_joint[s0 * C], 64u);
+        } else {
+            atomicAdd(&s_joint[slot * C + copy], 1u);
+        }
+    };
+    auto count_key_checked = [&](uint32_t k, uint32_t region0) {
+        add_field_checked((digit_at<R>(k, 0) << 3) | region0);
+#pragma unroll
+        for (int p = 1; p < P; p++) add_field_checked(p * F + digit_at<R + 3>(k, (uint32_t)(R * p - 3)));
+    };
+    auto count_key_plain = [&](uint32_t k, uint32_t region0) {
         atomicAdd(&s_joint[((digit_at<R>(k, 0) << 3) | region0) * C + copy], 1u);
 #pragma unroll
         for (int p = 1; p < P; p++)
             atomicAdd(&s_joint[(p * F + digit_at<R + 3>(k, (uint32_t)(R * p - 3))) * C + copy], 1u);
+    };
+    auto count_key = [&](uint32_t k, uint32_t region0) { count_key_checked(k, region0); };   // tail path
+    // does any digit of this key look wave-uniform?  (P cheap tests per 16 keys)
+    auto looks_uniform = [&](uint32_t k) -> bool {
+        bool any = false;
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const uint32_t d = digit_at<R>(k, (uint32_t)(R * p));
+            any = any || __all(d == __builtin_amdgcn_readfirstlane(d));
+        }
+        return any;
     };
 
     // Software-pipelined: the next group of 16-byte loads is in flight while the current group's
@@ -208,10 +236,17 @@ __global__ void __launch_bounds__(kHistThreads) joint_histograms_kernel(const ui
             if (c + u < vec_chunks) {
                 // region0_keys is a multiple of the 1024-key chunk, so the chunk is in one region
                 const uint32_t region0 = ((c + u) * (uint32_t)(kHistThreads * 4)) / region0_keys;
-                count_key(cur[u].x, region0);
-                count_key(cur[u].y, region0);
-                count_key(cur[u].z, region0);
-                count_key(cur[u].w, region0);
+                if (looks_uniform(cur[u].x)) {
+                    count_key_checked(cur[u].x, region0);
+                    count_key_checked(cur[u].y, region0);
+                    count_key_checked(cur[u].z, region0);
+                    count_key_checked(cur[u].w, region0);
+                } else {
+                    count_key_plain(cur[u].x, region0);
+                    count_key_plain(cur[u].y, region0);
+                    count_key_plain(cur[u].z, region0);
+                    count_key_plain(cur[u].w, region0);
+                }
             }
         }
 #pragma unroll

@@ -243,11 +243,32 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     if (RANK == kRankLdsAdd) {
         // The returned old value is (same-digit keys in earlier rows) + (peers in lower lanes):
         // the K atomics are independent, so they issue back to back.
+        // A row whose 64 keys share one digit (constant or sorted input, dead digits) would
+        // serialise on one LDS word although its ranks are simply consecutive.  Only waves whose
+        // FIRST row is like that pay for testing every row; uniform random input takes the
+        // straight path, where the K atomics issue back to back.
+        const uint32_t d_first = digit_at<R>(key[0], shift);
+        if (__all(d_first == __builtin_amdgcn_readfirstlane(d_first))) {
 #pragma unroll
-        for (int i = 0; i < K; i++) {
-            const uint32_t d = digit_at<R>(key[i], shift);
-            rank[i] = __hip_atomic_fetch_add((lds_u32*)&s_cnt[wave * H + d], 1u, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_WAVEFRONT);
+            for (int i = 0; i < K; i++) {
+                const uint32_t d = digit_at<R>(key[i], shift);
+                const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+                if (__all(d == d0)) {
+                    const uint32_t before = s_cnt[wave * H + d0];
+                    rank[i] = before + lane;
+                    if (lane == 0) s_cnt[wave * H + d0] = before + 64u;
+                } else {
+                    rank[i] = __hip_atomic_fetch_add((lds_u32*)&s_cnt[wave * H + d], 1u, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                const uint32_t d = digit_at<R>(key[i], shift);
+                rank[i] = __hip_atomic_fetch_add((lds_u32*)&s_cnt[wave * H + d], 1u, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
         }
     } else {
         const uint64_t lane_bit = 1ull << lane;

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Sort time by key distribution (GPU box): the reference only ever tests uniform keys."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import lsdradixsort_amd as lsd
+from bench import mt19937_keys
+
+n = 1 << 28
+base = mt19937_keys(n, 0)
+cases = {
+    "uniform": lambda: base,
+    "sorted": lambda: np.sort(base),
+    "reverse": lambda: np.sort(base)[::-1].copy(),
+    "all_equal": lambda: np.full(n, 0x12345678, dtype=np.uint32),
+    "low8_only": lambda: base & np.uint32(0xFF),
+    "high8_only": lambda: base & np.uint32(0xFF000000),
+    "16_values_per_digit": lambda: base & np.uint32(0x0F0F0F0F),
+    "small_range_2^20": lambda: base & np.uint32(0xFFFFF),
+}
+for r in (8, 4):
+    ws = lsd.alloc_workspace(n, r)
+    for name, make in cases.items():
+        d0 = lsd.to_device(make())
+        times = []
+        for i in range(4):
+            d = d0.clone()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            lsd.GPULSDRadixSort(d, r, workspace=ws)
+            e1.record()
+            torch.cuda.synchronize()
+            if i:
+                times.append(e0.elapsed_time(e1))
+        u = d.to(torch.int64) & 0xFFFFFFFF
+        ok = bool((u[1:] >= u[:-1]).all())
+        lsd.lib().lsdsort_check_device(ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        print(f"r={r} {name:22s} {np.median(times):8.3f} ms  {n / np.median(times) / 1e6:8.1f} Gkeys/s  sorted={ok}", flush=True)
+        del d0, d, u
