@@ -161,27 +161,27 @@ hipError_t launch_scan_digit_counts(int radix_bits, int groups, const uint32_t* 
 // same work as a plain digit histogram with a table 8x as large.  Pass 0 has no previous digit:
 // its regions are by position, uniform for a whole 1024-key chunk.
 // ------------------------------------------------------------------------------------------
-template <int R>
-__global__ void __launch_bounds__(kHistThreads) joint_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
-                                                                       uint32_t region0_keys,
-                                                                       uint32_t* __restrict__ joint,
-                                                                       uint32_t vec_chunks)
+template <int R, int THREADS>
+__global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                                  uint32_t region0_keys, uint32_t* __restrict__ joint,
+                                                                  uint32_t vec_chunks)
 {
     constexpr int P = 32 / R;
-    constexpr int F = (1 << R) * kRegions;   // fields per pass
-    // Narrow digits put 64 lanes on 128 words per pass: replicate the table so that neighbouring
-    // lanes use different words (and banks); wide digits spread by themselves.
+    constexpr int B = region_bits_for_radix(R);
+    constexpr int F = (1 << R) << B;          // fields per pass: (digit, region)
+    // Narrow digits put 64 lanes on a few hundred words per pass: replicate the table so that
+    // neighbouring lanes use different words (and banks); wide digits spread by themselves.
     constexpr int C = F >= 1024 ? 1 : 4;
-    __shared__ uint32_t s_joint[P * F * C];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_joint[];   // [P][F][C]
     const uint32_t tid = threadIdx.x;
     const uint32_t copy = tid & (C - 1);
-    for (uint32_t j = tid; j < (uint32_t)(P * F * C); j += kHistThreads) s_joint[j] = 0;
+    for (uint32_t j = tid; j < (uint32_t)(P * F * C); j += THREADS) s_joint[j] = 0;
     __syncthreads();
 
     // Low-entropy fields (constant or sorted input, dead high digits) would serialise all 64 lanes
     // of a wave on one LDS word; when the whole wave agrees on a field, one lane adds 64 instead.
     // The agreement test is only paid by groups of keys whose FIRST key already shows it in some
-    // field (uniform random input takes the plain path with one test per 16 keys).
+    // digit (uniform random input takes the plain path with P tests per 16 keys).
     auto add_field_checked = [&](uint32_t slot) {
         const uint32_t s0 = __builtin_amdgcn_readfirstlane(slot);
         if (__builtin_amdgcn_read_exec() == ~0ull && __all(slot == s0)) {
@@ -191,18 +191,16 @@ __global__ void __launch_bounds__(kHistThreads) joint_histograms_kernel(const ui
         }
     };
     auto count_key_checked = [&](uint32_t k, uint32_t region0) {
-        add_field_checked((digit_at<R>(k, 0) << 3) | region0);
+        add_field_checked((digit_at<R>(k, 0) << B) | region0);
 #pragma unroll
-        for (int p = 1; p < P; p++) add_field_checked(p * F + digit_at<R + 3>(k, (uint32_t)(R * p - 3)));
+        for (int p = 1; p < P; p++) add_field_checked(p * F + digit_at<R + B>(k, (uint32_t)(R * p - B)));
     };
     auto count_key_plain = [&](uint32_t k, uint32_t region0) {
-        atomicAdd(&s_joint[((digit_at<R>(k, 0) << 3) | region0) * C + copy], 1u);
+        atomicAdd(&s_joint[((digit_at<R>(k, 0) << B) | region0) * C + copy], 1u);
 #pragma unroll
         for (int p = 1; p < P; p++)
-            atomicAdd(&s_joint[(p * F + digit_at<R + 3>(k, (uint32_t)(R * p - 3))) * C + copy], 1u);
+            atomicAdd(&s_joint[(p * F + digit_at<R + B>(k, (uint32_t)(R * p - B))) * C + copy], 1u);
     };
-    auto count_key = [&](uint32_t k, uint32_t region0) { count_key_checked(k, region0); };   // tail path
-    // does any digit of this key look wave-uniform?  (P cheap tests per 16 keys)
     auto looks_uniform = [&](uint32_t k) -> bool {
         bool any = false;
 #pragma unroll
@@ -215,27 +213,28 @@ __global__ void __launch_bounds__(kHistThreads) joint_histograms_kernel(const ui
 
     // Software-pipelined: the next group of 16-byte loads is in flight while the current group's
     // keys go through the LDS atomics, so the memory pipe and the LDS stay busy together.
+    constexpr int VPT = kHistVecPerThread;
     const uint4* __restrict__ keys4 = reinterpret_cast<const uint4*>(keys);
-    auto load_group = [&](uint32_t c, uint4 (&v)[kHistVecPerThread]) {
+    auto load_group = [&](uint32_t c, uint4 (&v)[VPT]) {
 #pragma unroll
-        for (int u = 0; u < kHistVecPerThread; u++) {
+        for (int u = 0; u < VPT; u++) {
             const uint32_t cc = c + u;
-            v[u] = cc < vec_chunks ? keys4[(size_t)cc * kHistThreads + tid] : make_uint4(0, 0, 0, 0);
+            v[u] = cc < vec_chunks ? keys4[(size_t)cc * THREADS + tid] : make_uint4(0, 0, 0, 0);
         }
     };
-    const uint32_t stride = gridDim.x * kHistVecPerThread;
-    uint32_t c = blockIdx.x * kHistVecPerThread;
-    uint4 cur[kHistVecPerThread];
+    const uint32_t stride = gridDim.x * VPT;
+    uint32_t c = blockIdx.x * VPT;
+    uint4 cur[VPT];
     if (c < vec_chunks) load_group(c, cur);
     while (c < vec_chunks) {
-        uint4 nxt[kHistVecPerThread];
+        uint4 nxt[VPT];
         const uint32_t cn = c + stride;
         if (cn < vec_chunks) load_group(cn, nxt);
 #pragma unroll
-        for (int u = 0; u < kHistVecPerThread; u++) {
+        for (int u = 0; u < VPT; u++) {
             if (c + u < vec_chunks) {
-                // region0_keys is a multiple of the 1024-key chunk, so the chunk is in one region
-                const uint32_t region0 = ((c + u) * (uint32_t)(kHistThreads * 4)) / region0_keys;
+                // region0_keys is a multiple of the chunk (THREADS*4 keys), so the chunk is in one region
+                const uint32_t region0 = ((c + u) * (uint32_t)(THREADS * 4)) / region0_keys;
                 if (looks_uniform(cur[u].x)) {
                     count_key_checked(cur[u].x, region0);
                     count_key_checked(cur[u].y, region0);
@@ -250,43 +249,59 @@ __global__ void __launch_bounds__(kHistThreads) joint_histograms_kernel(const ui
             }
         }
 #pragma unroll
-        for (int u = 0; u < kHistVecPerThread; u++) cur[u] = nxt[u];
+        for (int u = 0; u < VPT; u++) cur[u] = nxt[u];
         c = cn;
     }
     if (blockIdx.x == 0) {
-        const uint32_t tail_begin = vec_chunks * (kHistThreads * 4);
-        for (uint32_t i = tail_begin + tid; i < n; i += kHistThreads) count_key(keys[i], i / region0_keys);
+        const uint32_t tail_begin = vec_chunks * (THREADS * 4);
+        for (uint32_t i = tail_begin + tid; i < n; i += THREADS) count_key_checked(keys[i], i / region0_keys);
     }
     __syncthreads();
-    for (uint32_t j = tid; j < (uint32_t)(P * F); j += kHistThreads) {
-        uint32_t c = 0;
+    for (uint32_t j = tid; j < (uint32_t)(P * F); j += THREADS) {
+        uint32_t cnt = 0;
 #pragma unroll
-        for (int q = 0; q < C; q++) c += s_joint[j * C + q];
-        if (c) atomicAdd(&joint[j], c);
+        for (int q = 0; q < C; q++) cnt += s_joint[j * C + q];
+        if (cnt) atomicAdd(&joint[j], cnt);
     }
+}
+
+#ifndef LSD_R8_HIST_THREADS
+#define LSD_R8_HIST_THREADS 1024
+#endif
+
+template <int R, int THREADS>
+static hipError_t launch_joint_inst(const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* joint,
+                                    hipStream_t stream)
+{
+    constexpr int P = 32 / R;
+    constexpr int F = (1 << R) << region_bits_for_radix(R);
+    constexpr int C = F >= 1024 ? 1 : 4;
+    constexpr size_t lds_bytes = (size_t)P * F * C * sizeof(uint32_t);
+    auto kernel = joint_histograms_kernel<R, THREADS>;
+    if (lds_bytes > 64 * 1024) {
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (attr != hipSuccess) return attr;
+    }
+    if (region0_keys == 0 || region0_keys % (THREADS * 4) != 0) return hipErrorInvalidValue;
+    const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
+    const uint32_t vec_chunks = aligned ? n / (THREADS * 4) : 0;
+    uint32_t blocks = (vec_chunks + kHistVecPerThread - 1) / kHistVecPerThread;
+    const uint32_t cap = (uint32_t)(2048 * 256 / THREADS);   // enough waves to cover HBM latency
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds_bytes, stream, keys, n, region0_keys, joint, vec_chunks);
+    return hipGetLastError();
 }
 
 hipError_t launch_joint_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys,
                                    uint32_t* joint, hipStream_t stream)
 {
-    if (region0_keys == 0 || region0_keys % (kHistThreads * 4) != 0) return hipErrorInvalidValue;
-    const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
-    const uint32_t vec_chunks = aligned ? n / (kHistThreads * 4) : 0;
-    uint32_t blocks = (vec_chunks + kHistVecPerThread - 1) / kHistVecPerThread;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks == 0) blocks = 1;
     switch (radix_bits) {
-        case 4:
-            hipLaunchKernelGGL((joint_histograms_kernel<4>), dim3(blocks), dim3(kHistThreads), 0, stream, keys, n,
-                               region0_keys, joint, vec_chunks);
-            break;
-        case 8:
-            hipLaunchKernelGGL((joint_histograms_kernel<8>), dim3(blocks), dim3(kHistThreads), 0, stream, keys, n,
-                               region0_keys, joint, vec_chunks);
-            break;
+        case 4: return launch_joint_inst<4, 256>(keys, n, region0_keys, joint, stream);
+        case 8: return launch_joint_inst<8, (LSD_R8_REGION_BITS == 3 ? 256 : LSD_R8_HIST_THREADS)>(keys, n, region0_keys, joint, stream);   // 32 KiB of counters per workgroup at 3 bits
         default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -325,9 +340,9 @@ __global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __res
         s_base[tid] = digit_base;
         uint32_t run = digit_base;
 #pragma unroll
-        for (int x = 0; x < kRegions; x++) {
+        for (int x = 0; x < REG; x++) {
             table[kRegionHeaderWords + x * bins + tid] = run;
-            if (x < REG) run += per_region[x];
+            run += per_region[x];
         }
     }
     if (tid == 0) s_base[bins] = n;
@@ -336,14 +351,14 @@ __global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __res
     if (tid == 0) {
         auto write_extents = [&](uint32_t* t, auto start_of) {
             uint32_t off = 0;
-            for (int x = 0; x < kRegions; x++) {
+            for (int x = 0; x < REG; x++) {
                 const uint32_t lo = start_of(x), hi = start_of(x + 1);
                 const uint32_t len = hi - lo;
                 const uint32_t tiles = (len + tile_keys - 1) / tile_keys;
                 t[x] = lo;
-                t[8 + x] = len;
-                t[16 + x] = tiles;
-                t[24 + x] = off;
+                t[kMaxRegions + x] = len;
+                t[2 * kMaxRegions + x] = tiles;
+                t[3 * kMaxRegions + x] = off;
                 off += tiles;
             }
         };
@@ -359,10 +374,10 @@ __global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __res
         }
         if (pass + 1 < passes) {
             uint32_t* next = tables + (size_t)(pass + 1) * table_words;
-            if (REG == 1 || bins < kRegions) {
+            if (REG == 1) {
                 write_extents(next, [&](int x) { return x == 0 ? 0u : n; });
             } else {
-                const int per = bins / kRegions;
+                const int per = bins / REG;   // digits per region
                 write_extents(next, [&](int x) { return s_base[x * per]; });
             }
         }
@@ -372,15 +387,21 @@ __global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __res
 hipError_t launch_scan_regions(int radix_bits, int passes, int regions, const uint32_t* counts, uint32_t n,
                                uint32_t tile_keys, uint32_t region0_keys, uint32_t* tables, hipStream_t stream)
 {
-    if (radix_bits < 1 || radix_bits > 8 || (regions != 1 && regions != kRegions)) return hipErrorInvalidValue;
+    if (radix_bits < 1 || radix_bits > 8 || (regions != 1 && regions != regions_for_radix(radix_bits))) return hipErrorInvalidValue;
     const int bins = 1 << radix_bits;
     const uint32_t words = (uint32_t)region_table_words(radix_bits);
     if (regions == 1)
         hipLaunchKernelGGL((scan_regions_kernel<1>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
                            region0_keys, passes, tables, words);
+    else if (regions == 8)
+        hipLaunchKernelGGL((scan_regions_kernel<8>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
+                           region0_keys, passes, tables, words);
+    else if (regions == 16)
+        hipLaunchKernelGGL((scan_regions_kernel<16>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
+                           region0_keys, passes, tables, words);
     else
-        hipLaunchKernelGGL((scan_regions_kernel<kRegions>), dim3(passes), dim3(256), 0, stream, counts, bins, n,
-                           tile_keys, region0_keys, passes, tables, words);
+        hipLaunchKernelGGL((scan_regions_kernel<32>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
+                           region0_keys, passes, tables, words);
     return hipGetLastError();
 }
 

@@ -20,20 +20,32 @@ struct TileShape {
 // Compiled tile shapes for a radix; index 0 is the default.  Returns the count.
 int tile_shapes(int radix_bits, const TileShape** out);
 
-// Regions.  A pass's input is split into kRegions contiguous regions whose digit histograms are
-// known before the pass starts, so each region carries its own chained scan over its own tiles
-// and no tile ever needs anything from another region.  Workgroups serve the region of their own
-// XCD first (hardware XCC_ID), which keeps neighbouring runs in one L2 and keeps each chain short.
+// Regions.  A pass's input is split into contiguous regions whose digit histograms are known
+// before the pass starts, so each region carries its own chained scan over its own tiles and no
+// tile ever needs anything from another region.  Each XCD has its own share of the regions:
+// workgroups serve those first (hardware XCC_ID), which keeps neighbouring runs in one L2; and the
+// more chains there are, the fewer tiles are in flight on each, which is what the look-back's
+// waiting time is proportional to (measured: 64 tiles in flight per chain 4.4 us, 32 tiles 2.2 us).
 //   pass 0     : region x = positions [x*R0, (x+1)*R0), R0 a multiple of the tile size
-//   pass p >= 1: region x = keys whose digit p-1 has top three bits x -- contiguous in the
-//                array because pass p-1 just sorted on that digit; its histogram of digit p is
-//                a joint count of two key fields, so it is permutation-invariant and comes out
-//                of the same single upfront read as the plain digit histograms.
-// Radixes below 3 bits (and the multi-GPU partition) use one region, i.e. one chain.
-constexpr int kRegions = 8;
-// Per-pass region table, uint32 words: start[8] | len[8] | tiles[8] | tile_off[8] | base[8][2^R]
-constexpr int kRegionHeaderWords = 32;
-inline constexpr size_t region_table_words(int radix_bits) { return kRegionHeaderWords + (size_t)kRegions * ((size_t)1 << radix_bits); }
+//   pass p >= 1: region x = keys whose digit p-1 has top log2(regions) bits x -- contiguous in
+//                the array because pass p-1 just sorted on that digit; its histogram of digit p
+//                is a joint count of two key fields, so it is permutation-invariant and comes
+//                out of the same single upfront read as the plain digit histograms.
+// 8-bit digits: 8 regions (top three bits of the previous digit, one per XCD).  16 and 32 were
+// measured too: the look-back wait falls (4.4 -> 2.7 us per tile at 32) but the upfront joint
+// histogram grows with the table (32 KiB -> 128 KiB of LDS counters per workgroup: 0.36 -> 0.65 ms),
+// a net loss.  4-bit digits: 16 regions (the whole previous digit; the table stays tiny).  Narrower
+// digits and the multi-GPU partition: one region, i.e. one chain.
+constexpr int kMaxRegions = 32;
+constexpr int kXcds = 8;
+#ifndef LSD_R8_REGION_BITS
+#define LSD_R8_REGION_BITS 3
+#endif
+inline constexpr int region_bits_for_radix(int radix_bits) { return radix_bits == 8 ? LSD_R8_REGION_BITS : (radix_bits == 4 ? 4 : 0); }
+inline constexpr int regions_for_radix(int radix_bits) { return 1 << region_bits_for_radix(radix_bits); }
+// Per-pass region table, uint32 words: start[32] | len[32] | tiles[32] | tile_off[32] | base[regions][2^R]
+constexpr int kRegionHeaderWords = 4 * kMaxRegions;
+inline constexpr size_t region_table_words(int radix_bits) { return kRegionHeaderWords + (size_t)kMaxRegions * ((size_t)1 << radix_bits); }
 
 // Everything one rank-and-scatter launch needs.
 struct PassParams {
@@ -47,7 +59,7 @@ struct PassParams {
     // chained (onesweep) form
     const uint32_t* regions;     // this pass's region table (device, written by the scan kernel)
     uint32_t* status;            // [num_tiles][2^R] tile-status words (lsd_device.hpp)
-    uint32_t* tickets;           // [kRegions] arrival ticket dispensers for this pass (zeroed)
+    uint32_t* tickets;           // [kMaxRegions] arrival ticket dispensers for this pass (zeroed)
     uint32_t parity;             // pass parity for the status codes
     // staged form
     const uint32_t* global_off;  // [num_tiles][2^R] digit-major exclusive scan, block-major
@@ -80,13 +92,14 @@ hipError_t launch_digit_histograms(int radix_bits, int groups, uint32_t shift0, 
 hipError_t launch_scan_digit_counts(int radix_bits, int groups, const uint32_t* hist, uint32_t* base,
                                     hipStream_t stream);
 
-// Stage 1, onesweep with regions (radix 4 and 8): joint[p][(digit_p << 3) | region_p(key)] for every
-// pass in one read; `region0_keys` is R0 (pass-0 regions are by position).  joint must be zero on entry.
+// Stage 1, onesweep with regions (radix 4 and 8): joint[p][(digit_p << B) | region_p(key)], B =
+// region_bits_for_radix, for every pass in one read; `region0_keys` is R0 (pass-0 regions are by
+// position).  joint must be zero on entry.
 hipError_t launch_joint_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys,
                                    uint32_t* joint, hipStream_t stream);
 
-// Stage 2, onesweep: region tables of every pass from the joint counts (`regions` = 8) or from
-// plain digit histograms (`regions` = 1; passes may then be 1 for the multi-GPU partition).
+// Stage 2, onesweep: region tables of every pass from the joint counts (`regions` = 16 or 32) or
+// from plain digit histograms (`regions` = 1; passes may then be 1 for the multi-GPU partition).
 // counts: [passes][2^R][regions]; tables: [passes][region_table_words(R)].
 hipError_t launch_scan_regions(int radix_bits, int passes, int regions, const uint32_t* counts, uint32_t n,
                                uint32_t tile_keys, uint32_t region0_keys, uint32_t* tables, hipStream_t stream);

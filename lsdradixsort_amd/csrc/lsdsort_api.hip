@@ -39,15 +39,11 @@ constexpr size_t kAlign = 256;
 constexpr size_t kControlBytes = 256;            // u32[64]: [0] fault word
 constexpr uint32_t kMaxXcdChunk = 64;
 
-// Radixes whose passes are split into 8 regions (lsd_kernels.hpp); narrower digits have no
-// three top bits to split on and run as one region.
-bool uses_regions(int radix_bits) { return radix_bits == 4 || radix_bits == 8; }
-
 // Pass-0 regions are by position: R0 keys each, a multiple of the tile (hence of the histogram
 // kernel's 1024-key chunk), eight of them covering n.
-uint32_t region0_keys(size_t n, size_t tile)
+uint32_t region0_keys(size_t n, size_t tile, int regions)
 {
-    const size_t per = (n + lsd::kRegions - 1) / lsd::kRegions;
+    const size_t per = (n + regions - 1) / regions;
     const size_t tiles = (per + tile - 1) / tile;
     return (uint32_t)((tiles ? tiles : 1) * tile);
 }
@@ -103,11 +99,11 @@ Layout make_layout(size_t n, int radix_bits, bool pairs, int algorithm, const Ti
     L.control = off;
     off += kControlBytes;
     if (algorithm == LSDSORT_ALGO_ONESWEEP) {
-        L.regions = uses_regions(radix_bits) ? lsd::kRegions : 1;
-        L.rows = L.tiles + (uint32_t)lsd::kRegions;
-        L.region0 = region0_keys(n, tile);
+        L.regions = lsd::regions_for_radix(radix_bits);
+        L.rows = L.tiles + (uint32_t)L.regions;          // one ragged last tile per region at most
+        L.region0 = region0_keys(n, tile, L.regions);
         L.tickets = off;
-        off = align_up(off + passes * lsd::kRegions * sizeof(uint32_t));
+        off = align_up(off + passes * lsd::kMaxRegions * sizeof(uint32_t));
         L.counts = off;
         off = align_up(off + passes * bins * (size_t)L.regions * sizeof(uint32_t));
         L.status = off;
@@ -264,7 +260,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     if (algorithm == LSDSORT_ALGO_ONESWEEP) {
         uint32_t* counts = reinterpret_cast<uint32_t*>(ws + L.counts);
         tables = reinterpret_cast<uint32_t*>(ws + L.tables);
-        if (L.regions == lsd::kRegions)
+        if (L.regions > 1)
             LSD_HIP(lsd::launch_joint_histograms(radix_bits, d_keys, (uint32_t)n, L.region0, counts, stream));
         else
             LSD_HIP(lsd::launch_digit_histograms(radix_bits, passes, 0, d_keys, (uint32_t)n, counts, stream));
@@ -297,7 +293,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             p.num_tiles = L.rows;
             p.regions = tables + (size_t)pass * table_words;
             p.status = reinterpret_cast<uint32_t*>(ws + L.status);
-            p.tickets = reinterpret_cast<uint32_t*>(ws + L.tickets) + (size_t)pass * lsd::kRegions;
+            p.tickets = reinterpret_cast<uint32_t*>(ws + L.tickets) + (size_t)pass * lsd::kMaxRegions;
             // The status rows a pass uses depend on its regions, so a row may sit out a pass; the
             // parity-coded reuse of lsd_device.hpp needs every word rewritten every pass.  Clear
             // instead: rows * 2^R words, about 1 % of the pass's traffic.
@@ -379,7 +375,7 @@ MsbLayout make_msb_layout(size_t n, int msb_bits)
     const int r = msb_bits ? msb_bits : 1;
     const TileShape* shape = current_shape(r);
     const size_t tile = (size_t)shape->tile();
-    L.rows = (uint32_t)((n + tile - 1) / tile) + (uint32_t)lsd::kRegions;
+    L.rows = (uint32_t)((n + tile - 1) / tile) + 1u;
     L.zero_bytes = align_up(L.status + (size_t)L.rows * ((size_t)1 << r) * sizeof(uint32_t));
     L.table = L.zero_bytes;
     L.total = align_up(L.table + lsd::region_table_words(r) * sizeof(uint32_t));

@@ -95,7 +95,11 @@ constexpr int rank_scatter_lds_words()
     constexpr int keys_words = CAP;
     constexpr int tab_words = RANK == kRankLdsOr ? W * H * 2 : 0;
     constexpr int buf = keys_words > tab_words ? keys_words : tab_words;
+#ifdef LSD_LDS_PAD_WORDS
+    return buf + W * H + H + 32 + LSD_LDS_PAD_WORDS;
+#else
     return buf + W * H + H + 32;
+#endif
 }
 
 template <int R, int T, int K, int CAP, int RANK, bool PAIRS, bool CHAINED>
@@ -159,13 +163,17 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             uint32_t xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             uint32_t got = 0xFFFFFFFFu;
-            for (uint32_t a = 0; a < (uint32_t)kRegions; a++) {
-                const uint32_t x = (xcc + a) & (uint32_t)(kRegions - 1);
+            // home regions of this XCD first (spread over them by block index), then everyone else's
+            constexpr uint32_t NREG = (uint32_t)regions_for_radix(R);
+            constexpr uint32_t PER_XCD = NREG >= (uint32_t)kXcds ? NREG / (uint32_t)kXcds : 1u;
+            const uint32_t home = NREG >= (uint32_t)kXcds ? (xcc & (uint32_t)(kXcds - 1)) * PER_XCD + (blockIdx.x / (uint32_t)kXcds) % PER_XCD : 0u;
+            for (uint32_t a = 0; a < NREG; a++) {
+                const uint32_t x = (home + a) % NREG;
                 // ticket and region extents in ONE round trip: the ticket is taken before the tile
                 // count is known (an over-run ticket of an exhausted or empty region is harmless)
                 const uint32_t ticket = atomicAdd(p.tickets + x, 1u);
-                const uint32_t region_tiles = p.regions[16 + x];
-                const uint32_t r_start = p.regions[x], r_len = p.regions[8 + x], row0 = p.regions[24 + x];
+                const uint32_t region_tiles = p.regions[2 * kMaxRegions + x];
+                const uint32_t r_start = p.regions[x], r_len = p.regions[kMaxRegions + x], row0 = p.regions[3 * kMaxRegions + x];
                 if (ticket < region_tiles) {
                     got = x;
                     s_misc[24] = r_start;
@@ -314,7 +322,76 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     const uint32_t c_stale = code_stale(parity);
     const uint32_t c_prefix = code_prefix(parity);
     uint32_t gbase = 0;
-    if (tid < (uint32_t)H) {
+    if (CHAINED && H <= 16) {
+        // Narrow digits: a status row is only 2^R words, so the whole of wave 0 walks together --
+        // lane (q, d) = q * H + d reads rows j - q*LB - l of digit d, i.e. 64/H * LB rows per step
+        // at the price of one round trip, and the partial results are chained with shuffles.
+        constexpr int QL = kWave / H;
+        if (tid < (uint32_t)kWave) {
+            const uint32_t d = lane % (uint32_t)H, q = lane / (uint32_t)H;
+            const uint32_t* const status_col = p.status + (size_t)chain_row0 * H + d;
+            uint32_t* const my_status = p.status + (size_t)tile * H + d;
+            const uint32_t my_total = __shfl(pub_total, (int)d, kWave);   // digit d's total lives in lane d
+            uint32_t excl = 0;
+            if (chain_pos == 0) {
+                if (q == 0) store_status(my_status, (my_total << 2) | c_prefix);
+            } else {
+                if (q == 0) store_status(my_status, (my_total << 2) | code_aggregate(parity));
+                int32_t j = (int32_t)chain_pos - 1;
+                uint32_t spins = 0;
+                bool found = false;
+                while (!found) {
+                    uint32_t sum = 0, consumed = 0;
+                    bool hit = false;
+                    const int32_t j0 = j - (int32_t)(q * LB);
+                    uint32_t window[LB];
+#pragma unroll
+                    for (int l = 0; l < LB; l++)
+                        window[l] = (j0 - l >= 0) ? load_status(status_col + (size_t)(j0 - l) * H) : c_stale;
+#pragma unroll
+                    for (int l = 0; l < LB; l++) {
+                        const uint32_t code = window[l] & 3u;
+                        if (!hit && consumed == (uint32_t)l && code != c_stale) {
+                            sum += window[l] >> 2;
+                            consumed = l + 1;
+                            hit = (code == c_prefix) || (j0 - l == 0);
+                        }
+                    }
+                    // chain the QL partial walks of this digit in order
+                    uint32_t step_sum = 0, step_rows = 0;
+                    bool alive = true;
+#pragma unroll
+                    for (int qq = 0; qq < QL; qq++) {
+                        const uint32_t sq = __shfl(sum, (int)(d + qq * H), kWave);
+                        const uint32_t cq = __shfl(consumed, (int)(d + qq * H), kWave);
+                        const uint32_t hq = __shfl((uint32_t)hit, (int)(d + qq * H), kWave);
+                        if (alive) {
+                            step_sum += sq;
+                            step_rows += cq;
+                            if (hq) {
+                                found = true;
+                                alive = false;
+                            } else if (cq < (uint32_t)LB) {
+                                alive = false;
+                            }
+                        }
+                    }
+                    excl += step_sum;
+                    j -= (int32_t)step_rows;
+                    if (tid == 0) LSD_COUNT(7, 1);
+                    if (!found && step_rows == 0) {
+                        if (++spins > kSpinLimit) {
+                            atomicOr(p.fault, 1u);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                if (q == 0) store_status(my_status, ((excl + my_total) << 2) | c_prefix);
+            }
+            gbase = p.regions[kRegionHeaderWords + region * H + d] + excl;   // lanes 0..H-1 are (q = 0, d = tid)
+        }
+    } else if (tid < (uint32_t)H) {
         if (CHAINED) {
             const uint32_t* const status_col = p.status + (size_t)chain_row0 * H + tid;   // this digit's column
             uint32_t* const my_status = p.status + (size_t)tile * H + tid;
