@@ -671,7 +671,7 @@ hipError_t launch_rank_scatter_r4(int shape_id, int rank_method, bool chained, c
 hipError_t launch_rank_scatter_small(int radix_bits, int rank_method, bool chained, const PassParams& p, hipStream_t stream);
 
 // Slot 0 is the default; the others stay compiled for tools/tune.py (DESIGN.md has the sweep).
-static const TileShape kShapesR8[] = {{1024, 16}, {512, 32}, {1024, 32}, {512, 16}, {1024, 32}, {256, 16}};
+static const TileShape kShapesR8[] = {{512, 32}, {1024, 16}, {1024, 32}, {512, 16}, {1024, 32}, {256, 16}};
 static const TileShape kShapesR4[] = {{512, 32}, {512, 16}, {256, 16}, {1024, 32}};
 static const TileShape kShapesSmall[] = {{256, 16}};
 

@@ -80,11 +80,15 @@ constexpr int min_waves_per_simd()
     return K <= 16 ? (T <= 512 ? 7 : 8) : (K <= 32 ? 4 : 2);
 }
 
-// Look-back geometry: status rows a thread reads per step of its walk.
+// Look-back geometry: LB status rows per thread per step; the first step is taken by up to four
+// "slots" of threads at once (thread t: digit t % H, slot t / H), so it covers SLOTS*LB predecessors
+// with one round trip.
 template <int R, int T>
 struct Lookback {
     static constexpr int H = 1 << R;
     static constexpr int LB = H >= 64 ? 4 : 8;
+    static constexpr int SLOTS = 1;   // measured: helper slots (2 or 4) buy nothing here, the extra barrier costs a little
+    static constexpr int LDS_WORDS = (SLOTS - 1) * LB * H;
 };
 
 template <int R, int T, int K, int CAP, int RANK>
@@ -95,11 +99,7 @@ constexpr int rank_scatter_lds_words()
     constexpr int keys_words = CAP;
     constexpr int tab_words = RANK == kRankLdsOr ? W * H * 2 : 0;
     constexpr int buf = keys_words > tab_words ? keys_words : tab_words;
-#ifdef LSD_LDS_PAD_WORDS
-    return buf + W * H + H + 32 + LSD_LDS_PAD_WORDS;
-#else
-    return buf + W * H + H + 32;
-#endif
+    return buf + W * H + H + 32 + Lookback<R, T>::LDS_WORDS;
 }
 
 template <int R, int T, int K, int CAP, int RANK, bool PAIRS, bool CHAINED>
@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     constexpr int TAB_WORDS = RANK == kRankLdsOr ? W * H * 2 : 0;
     constexpr int BUF_WORDS = KEYS_WORDS > TAB_WORDS ? KEYS_WORDS : TAB_WORDS;
     constexpr int LB = Lookback<R, T>::LB;          // status rows per thread per look-back step
+    constexpr int LSLOTS = Lookback<R, T>::SLOTS;   // thread slots sharing the first step
     static_assert(T % kWave == 0 && H <= T, "one thread per digit in the tile scan");
     static_assert(TILE % CAP == 0 && CAP % T == 0 && (CAP & (CAP - 1)) == 0, "rounds must tile the tile");
 
@@ -130,6 +131,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     volatile lds_u32* const s_cnt = (volatile lds_u32*)(s_base + BUF_WORDS);  // [W][H] counters, then wave bases
     lds_u32* const s_gdelta = s_base + BUF_WORDS + W * H;             // [H] global base - local offset
     lds_u32* const s_misc = s_gdelta + H;                             // [1..17] wave totals, [24..29] claimed tile
+    lds_u32* const s_look = s_misc + 32;                              // [LSLOTS-1][LB][H] first-step status rows
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -311,132 +313,27 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     uint32_t pub_total = total;
     if (tid == (uint32_t)(H - 1)) pub_total -= (uint32_t)TILE - valid;
 
-    // ---- 4. tile base per digit ("global offsets", .cu:885-894) ----------------------------------
-    // Chained form: publish this tile's counts, then AT ONCE walk back over the chain until an
-    // inclusive prefix is met, and publish ours.  The walk comes before everything else on purpose:
-    // how many predecessors a tile must add up is (time between a tile's two publications) / (time
-    // between two tiles entering the chain), so any work put between the two publications is paid
-    // again by every successor as extra status rows to read (measured: with the reorder below in
-    // between, 28 rows per tile instead of 4).
     const uint32_t parity = p.parity;
     const uint32_t c_stale = code_stale(parity);
     const uint32_t c_prefix = code_prefix(parity);
-    uint32_t gbase = 0;
-    if (CHAINED && H <= 16) {
-        // Narrow digits: a status row is only 2^R words, so the whole of wave 0 walks together --
-        // lane (q, d) = q * H + d reads rows j - q*LB - l of digit d, i.e. 64/H * LB rows per step
-        // at the price of one round trip, and the partial results are chained with shuffles.
-        constexpr int QL = kWave / H;
-        if (tid < (uint32_t)kWave) {
-            const uint32_t d = lane % (uint32_t)H, q = lane / (uint32_t)H;
-            const uint32_t* const status_col = p.status + (size_t)chain_row0 * H + d;
-            uint32_t* const my_status = p.status + (size_t)tile * H + d;
-            const uint32_t my_total = __shfl(pub_total, (int)d, kWave);   // digit d's total lives in lane d
-            uint32_t excl = 0;
-            if (chain_pos == 0) {
-                if (q == 0) store_status(my_status, (my_total << 2) | c_prefix);
-            } else {
-                if (q == 0) store_status(my_status, (my_total << 2) | code_aggregate(parity));
-                int32_t j = (int32_t)chain_pos - 1;
-                uint32_t spins = 0;
-                bool found = false;
-                while (!found) {
-                    uint32_t sum = 0, consumed = 0;
-                    bool hit = false;
-                    const int32_t j0 = j - (int32_t)(q * LB);
-                    uint32_t window[LB];
-#pragma unroll
-                    for (int l = 0; l < LB; l++)
-                        window[l] = (j0 - l >= 0) ? load_status(status_col + (size_t)(j0 - l) * H) : c_stale;
-#pragma unroll
-                    for (int l = 0; l < LB; l++) {
-                        const uint32_t code = window[l] & 3u;
-                        if (!hit && consumed == (uint32_t)l && code != c_stale) {
-                            sum += window[l] >> 2;
-                            consumed = l + 1;
-                            hit = (code == c_prefix) || (j0 - l == 0);
-                        }
-                    }
-                    // chain the QL partial walks of this digit in order
-                    uint32_t step_sum = 0, step_rows = 0;
-                    bool alive = true;
-#pragma unroll
-                    for (int qq = 0; qq < QL; qq++) {
-                        const uint32_t sq = __shfl(sum, (int)(d + qq * H), kWave);
-                        const uint32_t cq = __shfl(consumed, (int)(d + qq * H), kWave);
-                        const uint32_t hq = __shfl((uint32_t)hit, (int)(d + qq * H), kWave);
-                        if (alive) {
-                            step_sum += sq;
-                            step_rows += cq;
-                            if (hq) {
-                                found = true;
-                                alive = false;
-                            } else if (cq < (uint32_t)LB) {
-                                alive = false;
-                            }
-                        }
-                    }
-                    excl += step_sum;
-                    j -= (int32_t)step_rows;
-                    if (tid == 0) LSD_COUNT(7, 1);
-                    if (!found && step_rows == 0) {
-                        if (++spins > kSpinLimit) {
-                            atomicOr(p.fault, 1u);
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                }
-                if (q == 0) store_status(my_status, ((excl + my_total) << 2) | c_prefix);
-            }
-            gbase = p.regions[kRegionHeaderWords + region * H + d] + excl;   // lanes 0..H-1 are (q = 0, d = tid)
-        }
-    } else if (tid < (uint32_t)H) {
-        if (CHAINED) {
-            const uint32_t* const status_col = p.status + (size_t)chain_row0 * H + tid;   // this digit's column
-            uint32_t* const my_status = p.status + (size_t)tile * H + tid;
-            uint32_t excl = 0;
-            if (chain_pos == 0) {
-                store_status(my_status, (pub_total << 2) | c_prefix);
-            } else {
-                store_status(my_status, (pub_total << 2) | code_aggregate(parity));
-                int32_t j = (int32_t)chain_pos - 1;   // nearest predecessor not yet consumed
-                uint32_t spins = 0;
-                bool found = false;
-                while (!found) {
-                    uint32_t window[LB];
-#pragma unroll
-                    for (int l = 0; l < LB; l++)
-                        window[l] = (j - l >= 0) ? load_status(status_col + (size_t)(j - l) * H) : c_stale;
-                    int consumed = 0;
-#pragma unroll
-                    for (int l = 0; l < LB; l++) {
-                        const uint32_t code = window[l] & 3u;
-                        if (!found && consumed == l && code != c_stale) {
-                            excl += window[l] >> 2;
-                            consumed = l + 1;
-                            found = (code == c_prefix) || (j - l == 0);
-                        }
-                    }
-                    if (tid == 0) LSD_COUNT(7, 1);
-                    if (consumed == 0) {
-                        if (++spins > kSpinLimit) {
-                            atomicOr(p.fault, 1u);
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                        if (tid == 0) LSD_COUNT(8, 1);
-                    }
-                    j -= consumed;
-                }
-                store_status(my_status, ((excl + pub_total) << 2) | c_prefix);
-            }
-            gbase = p.regions[kRegionHeaderWords + region * H + tid] + excl;
-        } else {
-            gbase = p.global_off[(size_t)tile * H + tid];
-        }
+    // this thread's (digit, slot) column of its region's chain
+    const uint32_t my_digit = tid % (uint32_t)H;
+    const uint32_t my_slot = tid / (uint32_t)H;
+    const uint32_t* const status_col = CHAINED ? p.status + (size_t)chain_row0 * H + my_digit : nullptr;
+    uint32_t window[LB];
+    int32_t j = (int32_t)chain_pos - 1;   // nearest predecessor in the chain not yet consumed
+    if (CHAINED && tid < (uint32_t)H) {
+        // publish as early as possible: successors can already add this tile's counts
+        const uint32_t code = chain_pos == 0 ? c_prefix : code_aggregate(parity);
+        store_status(p.status + (size_t)tile * H + tid, (pub_total << 2) | code);
     }
-    LSD_STAMP(5);   // publish + look-back (wave 0's digits)
+    if (CHAINED && my_slot < (uint32_t)LSLOTS) {
+        // first look-back step, issued now and consumed after the LDS reorder below: slot s covers
+        // predecessors j - s*LB - l, so LSLOTS*LB status rows cost one round trip
+        const int32_t j0 = j - (int32_t)(my_slot * LB);
+#pragma unroll
+        for (int l = 0; l < LB; l++) window[l] = (j0 - l >= 0) ? load_status(status_col + (size_t)(j0 - l) * H) : c_stale;
+    }
 
     uint32_t incl = wave_inclusive_scan(tid < (uint32_t)H ? total : 0u, lane);
     if (H > kWave) {
@@ -452,10 +349,9 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     if (tid < (uint32_t)H) {
 #pragma unroll
         for (int w = 0; w < W; w++) s_cnt[w * H + tid] = local_off + wave_excl[w];
-        s_gdelta[tid] = gbase - local_off;
     }
     lds_barrier();
-    LSD_STAMP(3);   // scan, bases
+    LSD_STAMP(3);   // totals, publish, scan, bases
 
     // payload loads go out now; they land while the keys are reordered
     uint32_t val[PAIRS ? K : 1];
@@ -495,8 +391,74 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             if (ROUNDS == 1 || (pos[i] / (uint32_t)CAP) == (uint32_t)round) s_keys[pos[i] % (uint32_t)CAP] = key[i];
         }
 
+        if (round == 0) {
+            LSD_STAMP(4);   // first round's LDS writes
+            // ---- 4. tile base per digit ("global offsets", .cu:885-894) ----------------------------
+            if (CHAINED && LSLOTS > 1) {
+                // the helper slots hand their share of the first step to the digit's owner
+                if (my_slot >= 1 && my_slot < (uint32_t)LSLOTS) {
+#pragma unroll
+                    for (int l = 0; l < LB; l++) s_look[((my_slot - 1) * LB + l) * H + my_digit] = window[l];
+                }
+                lds_barrier();
+            }
+            if (tid < (uint32_t)H) {
+                uint32_t gbase;
+                if (CHAINED) {
+                    uint32_t excl = 0;
+                    if (chain_pos > 0) {
+                        // first step: own window, then the helper slots' rows, in chain order
+                        int consumed = 0;
+                        bool found = false;
+#pragma unroll
+                        for (int m = 0; m < LSLOTS * LB; m++) {
+                            const uint32_t word = m < LB ? window[m] : s_look[(m - LB) * H + tid];
+                            const uint32_t code = word & 3u;
+                            if (!found && consumed == m && code != c_stale) {
+                                excl += word >> 2;
+                                consumed = m + 1;
+                                found = (code == c_prefix) || (j - m == 0);
+                            }
+                        }
+                        j -= consumed;
+                        uint32_t spins = 0;
+                        while (!found) {
+                            // further steps: LB rows at a time by the owner alone
+#pragma unroll
+                            for (int l = 0; l < LB; l++)
+                                window[l] = (j - l >= 0) ? load_status(status_col + (size_t)(j - l) * H) : c_stale;
+                            consumed = 0;
+#pragma unroll
+                            for (int l = 0; l < LB; l++) {
+                                const uint32_t code = window[l] & 3u;
+                                if (!found && consumed == l && code != c_stale) {
+                                    excl += window[l] >> 2;
+                                    consumed = l + 1;
+                                    found = (code == c_prefix) || (j - l == 0);
+                                }
+                            }
+                            if (tid == 0) LSD_COUNT(7, 1);
+                            if (consumed == 0) {
+                                if (++spins > kSpinLimit) {
+                                    atomicOr(p.fault, 1u);
+                                    break;
+                                }
+                                __builtin_amdgcn_s_sleep(1);
+                                if (tid == 0) LSD_COUNT(8, 1);
+                            }
+                            j -= consumed;
+                        }
+                        store_status(p.status + (size_t)tile * H + tid, ((excl + pub_total) << 2) | c_prefix);
+                    }
+                    gbase = p.regions[kRegionHeaderWords + region * H + tid] + excl;
+                } else {
+                    gbase = p.global_off[(size_t)tile * H + tid];
+                }
+                s_gdelta[tid] = gbase - local_off;
+            }
+        }
         lds_barrier();
-        if (round == 0) LSD_STAMP(4);   // first round's LDS writes + barrier
+        if (round == 0) LSD_STAMP(5);   // look-back (wave 0's digits) + barrier
 
         // linear read-back: consecutive threads hold consecutive tile positions, so each digit's
         // keys leave as one contiguous run

@@ -7,8 +7,8 @@ namespace lsd {
 hipError_t launch_rank_scatter_r8(int shape_id, int rank_method, bool chained, const PassParams& p, hipStream_t stream)
 {
     switch (shape_id) {
-        case 0: return launch_rank_scatter_shape<8, 1024, 16, 8192>(rank_method, chained, p, stream);   // keys default
-        case 1: return launch_rank_scatter_shape<8, 512, 32, 16384>(rank_method, chained, p, stream);
+        case 0: return launch_rank_scatter_shape<8, 512, 32, 16384>(rank_method, chained, p, stream);   // keys default
+        case 1: return launch_rank_scatter_shape<8, 1024, 16, 8192>(rank_method, chained, p, stream);
         case 2: return launch_rank_scatter_shape<8, 1024, 32, 16384>(rank_method, chained, p, stream);
         case 3: return launch_rank_scatter_shape<8, 512, 16, 8192>(rank_method, chained, p, stream);
         case 4: return launch_rank_scatter_shape<8, 1024, 32, 32768>(rank_method, chained, p, stream);  // key/value default
