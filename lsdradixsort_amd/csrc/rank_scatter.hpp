@@ -171,10 +171,13 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             const uint32_t home = NREG >= (uint32_t)kXcds ? (xcc & (uint32_t)(kXcds - 1)) * PER_XCD + (blockIdx.x / (uint32_t)kXcds) % PER_XCD : 0u;
             for (uint32_t a = 0; a < NREG; a++) {
                 const uint32_t x = (home + a) % NREG;
-                // ticket and region extents in ONE round trip: the ticket is taken before the tile
-                // count is known (an over-run ticket of an exhausted or empty region is harmless)
-                const uint32_t ticket = atomicAdd(p.tickets + x, 1u);
+                // Home region: ticket and extents in ONE round trip (the ticket is taken before the
+                // tile count is known; an over-run ticket of an exhausted region is harmless).
+                // Other regions: look at the (cached) tile count first, so that walking past empty
+                // regions (skewed digits leave most of them empty) costs loads, not atomics.
                 const uint32_t region_tiles = p.regions[2 * kMaxRegions + x];
+                if (a > 0 && region_tiles == 0) continue;
+                const uint32_t ticket = atomicAdd(p.tickets + x, 1u);
                 const uint32_t r_start = p.regions[x], r_len = p.regions[kMaxRegions + x], row0 = p.regions[3 * kMaxRegions + x];
                 if (ticket < region_tiles) {
                     got = x;
