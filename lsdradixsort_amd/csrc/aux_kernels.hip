@@ -191,12 +191,12 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
         }
     };
     auto count_key_checked = [&](uint32_t k, uint32_t region0) {
-        add_field_checked((digit_at<R>(k, 0) << B) | region0);
+        add_field_checked((region0 << R) | digit_at<R>(k, 0));   // pass 0: region-major in LDS (see flush)
 #pragma unroll
         for (int p = 1; p < P; p++) add_field_checked(p * F + digit_at<R + B>(k, (uint32_t)(R * p - B)));
     };
     auto count_key_plain = [&](uint32_t k, uint32_t region0) {
-        atomicAdd(&s_joint[((digit_at<R>(k, 0) << B) | region0) * C + copy], 1u);
+        atomicAdd(&s_joint[((region0 << R) | digit_at<R>(k, 0)) * C + copy], 1u);
 #pragma unroll
         for (int p = 1; p < P; p++)
             atomicAdd(&s_joint[(p * F + digit_at<R + B>(k, (uint32_t)(R * p - B))) * C + copy], 1u);
@@ -257,10 +257,15 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
         for (uint32_t i = tail_begin + tid; i < n; i += THREADS) count_key_checked(keys[i], i / region0_keys);
     }
     __syncthreads();
+    // Flush.  Pass 0's fields sit region-major in LDS: all 64 lanes of a wave share their position
+    // region, so with the region in the low index bits they would share four LDS banks; the global
+    // table is digit-major for every pass.
     for (uint32_t j = tid; j < (uint32_t)(P * F); j += THREADS) {
+        uint32_t src = j;
+        if (j < (uint32_t)F) src = ((j & (uint32_t)((1 << B) - 1)) << R) | (j >> B);
         uint32_t cnt = 0;
 #pragma unroll
-        for (int q = 0; q < C; q++) cnt += s_joint[j * C + q];
+        for (int q = 0; q < C; q++) cnt += s_joint[src * C + q];
         if (cnt) atomicAdd(&joint[j], cnt);
     }
 }
