@@ -59,6 +59,7 @@ struct PassParams {
     // chained (onesweep) form
     const uint32_t* regions;     // this pass's region table (device, written by the scan kernel)
     uint32_t* status;            // [num_tiles][2^R] tile-status words (lsd_device.hpp)
+    uint32_t* status_clear;      // the next pass's status array: workgroup b zeroes row b; may be null
     uint32_t* tickets;           // [kMaxRegions] arrival ticket dispensers for this pass (zeroed)
     uint32_t parity;             // pass parity for the status codes
     // staged form

@@ -73,8 +73,9 @@ struct Layout {
     size_t control = 0;      // fault word
     size_t tickets = 0;      // onesweep: [P][8] arrival ticket dispensers
     size_t counts = 0;       // onesweep: [P][H][regions] joint / digit counts
-    size_t status = 0;       // onesweep: [rows][H] tile-status words
+    size_t status = 0;       // onesweep: [rows][H] tile-status words, even passes
     size_t zero_bytes = 0;
+    size_t status_odd = 0;   // onesweep: the same for odd passes (cleared by the even pass before it, and vice versa)
     size_t tables = 0;       // onesweep: [P] region tables
     size_t tile_hist = 0;    // staged: [tiles][H] counts, then local offsets in place
     size_t tile_global = 0;  // staged: [tiles][H] global offsets
@@ -109,6 +110,8 @@ Layout make_layout(size_t n, int radix_bits, bool pairs, int algorithm, const Ti
         L.status = off;
         off = align_up(off + (size_t)L.rows * bins * sizeof(uint32_t));
         L.zero_bytes = off;
+        L.status_odd = off;
+        off = align_up(off + (size_t)L.rows * bins * sizeof(uint32_t));
         L.tables = off;
         off = align_up(off + passes * lsd::region_table_words(radix_bits) * sizeof(uint32_t));
     } else {
@@ -292,14 +295,16 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
         if (algorithm == LSDSORT_ALGO_ONESWEEP) {
             p.num_tiles = L.rows;
             p.regions = tables + (size_t)pass * table_words;
-            p.status = reinterpret_cast<uint32_t*>(ws + L.status);
+            // The status rows a pass uses depend on its regions, so a row may sit out a pass and the
+            // parity-coded reuse of lsd_device.hpp (every word rewritten every pass) does not apply.
+            // Two status arrays instead: a pass works in one and its workgroups clear the other, one
+            // row each (the grid has exactly `rows` workgroups), for the pass after it -- 1 KiB of plain
+            // stores per 64 KiB tile and no launch between the passes.  The sort's opening memset
+            // covers the even array.
+            p.status = reinterpret_cast<uint32_t*>(ws + ((pass & 1) ? L.status_odd : L.status));
+            p.status_clear = pass + 1 < passes ? reinterpret_cast<uint32_t*>(ws + ((pass & 1) ? L.status : L.status_odd)) : nullptr;
             p.tickets = reinterpret_cast<uint32_t*>(ws + L.tickets) + (size_t)pass * lsd::kMaxRegions;
-            // The status rows a pass uses depend on its regions, so a row may sit out a pass; the
-            // parity-coded reuse of lsd_device.hpp needs every word rewritten every pass.  Clear
-            // instead: rows * 2^R words, about 1 % of the pass's traffic.
             p.parity = 0;
-            if (pass > 0)
-                LSD_HIP(hipMemsetAsync(ws + L.status, 0, (size_t)L.rows * ((size_t)1 << radix_bits) * sizeof(uint32_t), stream));
             LSD_HIP(lsd::launch_rank_scatter(radix_bits, *shape, rank_method, true, p, stream));
         } else {
             uint32_t* tile_hist = reinterpret_cast<uint32_t*>(ws + L.tile_hist);

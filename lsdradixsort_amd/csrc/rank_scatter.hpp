@@ -54,20 +54,27 @@ __device__ __forceinline__ void lds_barrier()
 // Diagnostic build only (make STATS=1 -> liblsdsort_stats.so, never the product): wave 0 of every
 // tile stamps s_memrealtime (100 MHz) at phase boundaries and adds the differences to
 // a per-tile record p.stats[tile][0..6]; [7] look-back refills, [8] empty polls (thread 0's digit).
+constexpr int kStatsStride = 16;   // [0..6] phases, [7] refills, [8] empty polls, [9] start, [10] rows walked,
+                                   // [11] t(prefix stored), [12] t(prefix met), [13] chain pos it was met at, [14] t(walk start)
 #ifdef LSD_PHASE_STATS
+#define LSD_SET(idx, v)                                                                     \
+    do {                                                                                    \
+        if (p.stats) p.stats[(size_t)stat_row__ * kStatsStride + (idx)] = (unsigned long long)(v); \
+    } while (0)
 #define LSD_STAMP(idx)                                                                      \
     do {                                                                                    \
         const unsigned long long now__ = __builtin_amdgcn_s_memrealtime();                  \
-        if (tid == 0 && p.stats) p.stats[(size_t)stat_row__ * 10 + (idx)] = now__ - stamp__; \
+        if (tid == 0 && p.stats) p.stats[(size_t)stat_row__ * kStatsStride + (idx)] = now__ - stamp__; \
         stamp__ = now__;                                                                    \
     } while (0)
 #define LSD_COUNT(idx, v)                                                                   \
     do {                                                                                    \
-        if (p.stats) p.stats[(size_t)stat_row__ * 10 + (idx)] += (unsigned long long)(v);   \
+        if (p.stats) p.stats[(size_t)stat_row__ * kStatsStride + (idx)] += (unsigned long long)(v);   \
     } while (0)
 #else
 #define LSD_STAMP(idx) do { } while (0)
 #define LSD_COUNT(idx, v) do { } while (0)
+#define LSD_SET(idx, v) do { } while (0)
 #endif
 
 // Register budget: a K=16 tile at 73 VGPRs lands exactly on the 6-waves-per-SIMD step, where a
@@ -86,7 +93,9 @@ constexpr int min_waves_per_simd()
 template <int R, int T>
 struct Lookback {
     static constexpr int H = 1 << R;
-    static constexpr int LB = H >= 64 ? 4 : 8;
+    // rows per step, measured on 2^28 keys (tools/ab_bench.sh): 2 -> 0.534, 4 -> 0.551, 8 -> 0.553 ms/pass at
+    // 8-bit digits: a step costs a round trip whatever its width, but every row is 1 KiB of status reads
+    static constexpr int LB = H >= 64 ? 2 : 8;
     static constexpr int SLOTS = 1;   // measured: helper slots (2 or 4) buy nothing here, the extra barrier costs a little
     static constexpr int LDS_WORDS = (SLOTS - 1) * LB * H;
 };
@@ -154,6 +163,11 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     uint32_t range_end;        // one past the last key this tile may touch
     uint32_t region = 0;
     uint32_t chain_row0 = 0;
+    if (CHAINED && p.status_clear) {
+        // housekeeping for the NEXT pass (it runs in the other status array): one row per workgroup
+#pragma unroll
+        for (uint32_t i = tid; i < (uint32_t)H; i += (uint32_t)T) p.status_clear[(size_t)blockIdx.x * H + i] = 0;
+    }
     if (CHAINED) {
         // A tile comes from a ticket taken on arrival from its region's dispenser, and it only ever
         // waits on earlier tickets of the SAME dispenser -- workgroups that have already started.
@@ -219,7 +233,13 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     }
 #ifdef LSD_PHASE_STATS
     stat_row__ = tile;
-    if (tid == 0 && p.stats) p.stats[(size_t)stat_row__ * 10 + 9] = stamp__;
+    if (tid == 0 && p.stats) {
+        p.stats[(size_t)stat_row__ * kStatsStride + 9] = stamp__;
+        // counters are per pass: the rows are reused by every pass of a sort
+        p.stats[(size_t)stat_row__ * kStatsStride + 7] = 0;
+        p.stats[(size_t)stat_row__ * kStatsStride + 8] = 0;
+        p.stats[(size_t)stat_row__ * kStatsStride + 10] = 0;
+    }
     LSD_STAMP(0);   // ticket
 #endif
 
@@ -230,14 +250,16 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     // ---- 1. load: wave-striped, so (register row, lane) order == key order ------------------------
     uint32_t key[K];
     const uint32_t first = tile_base + wave * (uint32_t)(kWave * K) + lane;
+    // one 64-bit base, constant offsets: an index sum per load would cost an address pair per load
+    const uint32_t* const keys_in = p.in + first;
     if (full) {
 #pragma unroll
-        for (int i = 0; i < K; i++) key[i] = p.in[first + i * kWave];
+        for (int i = 0; i < K; i++) key[i] = keys_in[i * kWave];
     } else {
 #pragma unroll
         for (int i = 0; i < K; i++) {
             const uint32_t idx = first + i * kWave;
-            key[i] = idx < range_end ? p.in[idx] : 0xFFFFFFFFu;
+            key[i] = idx < range_end ? keys_in[i * kWave] : 0xFFFFFFFFu;
         }
     }
 
@@ -356,26 +378,34 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     lds_barrier();
     LSD_STAMP(3);   // totals, publish, scan, bases
 
-    // payload loads go out now; they land while the keys are reordered
+    // Payload loads.  With a single reorder round they are issued only after the keys have gone to
+    // LDS (below), so a payload never shares the register file with a live key: 2 registers per
+    // pair instead of 3.  With several rounds keys stay live across rounds, so the payloads are
+    // fetched here and land while the keys are reordered.
     uint32_t val[PAIRS ? K : 1];
-    if (PAIRS) {
+    auto load_vals = [&]() {
+        const uint32_t* const vals_in = p.vals_in + first;
         if (full) {
 #pragma unroll
-            for (int i = 0; i < K; i++) val[i] = p.vals_in[first + i * kWave];
+            for (int i = 0; i < K; i++) val[i] = vals_in[i * kWave];
         } else {
 #pragma unroll
             for (int i = 0; i < K; i++) {
                 const uint32_t idx = first + i * kWave;
-                val[i] = idx < range_end ? p.vals_in[idx] : 0u;
+                val[i] = idx < range_end ? vals_in[i * kWave] : 0u;
             }
         }
-    }
+    };
+    if (PAIRS && ROUNDS > 1) load_vals();
 
     // ---- 5. reorder through LDS in ROUNDS rounds of CAP tile positions each ------------------
     // A key whose tile-sorted position is q belongs to round q / CAP, slot q % CAP.  Rounds are
     // by position, not by digit, so their size never depends on the key distribution; the tile
     // (and with it the length of every digit's run in global memory) can exceed the LDS buffer.
-    uint32_t pos[K];
+    // key/value tiles of up to 64 Ki positions keep them two to a register (PACKED): they have to
+    // survive until the payloads have gone through LDS as well
+    constexpr bool PACKED = PAIRS && ROUNDS == 1 && TILE <= 65536 && K % 2 == 0;
+    uint32_t pos[PACKED ? K / 2 : K];
 #pragma unroll
     for (int i = 0; i < K; i++) {
         // recompute the digit here: carrying K digits (or LDS addresses) over from the rank phase
@@ -383,16 +413,28 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         uint32_t kk = key[i];
         asm volatile("" : "+v"(kk));
         const uint32_t d = digit_at<R>(kk, shift);
-        pos[i] = s_cnt[wave * H + d] + rank[i];
+        const uint32_t q = s_cnt[wave * H + d] + rank[i];
+        if (!PACKED) pos[i] = q;
+        else if (i % 2 == 0) pos[i / 2] = q;
+        else pos[i / 2] |= q << 16;
     }
+    auto pos_at = [&](int i) -> uint32_t {
+        if (!PACKED) return pos[i];
+        // opaque to the optimiser: otherwise it keeps (and spills) the K LDS addresses of the key
+        // round for the payload round instead of unpacking again
+        uint32_t w = pos[i / 2];
+        asm volatile("" : "+v"(w));
+        return i % 2 == 0 ? (w & 0xFFFFu) : (w >> 16);
+    };
 
 #pragma unroll
     for (int round = 0; round < ROUNDS; round++) {
         if (round > 0) lds_barrier();   // the previous round has been read back
 #pragma unroll
         for (int i = 0; i < K; i++) {
-            if (ROUNDS == 1 || (pos[i] / (uint32_t)CAP) == (uint32_t)round) s_keys[pos[i] % (uint32_t)CAP] = key[i];
+            if (ROUNDS == 1 || (pos_at(i) / (uint32_t)CAP) == (uint32_t)round) s_keys[pos_at(i) % (uint32_t)CAP] = key[i];
         }
+        if (PAIRS && ROUNDS == 1) load_vals();   // the key registers are free now
 
         if (round == 0) {
             LSD_STAMP(4);   // first round's LDS writes
@@ -413,6 +455,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                         // first step: own window, then the helper slots' rows, in chain order
                         int consumed = 0;
                         bool found = false;
+                        if (tid == 0) LSD_SET(14, __builtin_amdgcn_s_memrealtime());
 #pragma unroll
                         for (int m = 0; m < LSLOTS * LB; m++) {
                             const uint32_t word = m < LB ? window[m] : s_look[(m - LB) * H + tid];
@@ -424,6 +467,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                             }
                         }
                         j -= consumed;
+                        if (tid == 0) LSD_COUNT(10, consumed);
                         uint32_t spins = 0;
                         while (!found) {
                             // further steps: LB rows at a time by the owner alone
@@ -450,8 +494,14 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                                 if (tid == 0) LSD_COUNT(8, 1);
                             }
                             j -= consumed;
+                            if (tid == 0) LSD_COUNT(10, consumed);
+                        }
+                        if (tid == 0) {
+                            LSD_SET(12, __builtin_amdgcn_s_memrealtime());
+                            LSD_SET(13, j + 1);
                         }
                         store_status(p.status + (size_t)tile * H + tid, ((excl + pub_total) << 2) | c_prefix);
+                        if (tid == 0) LSD_SET(11, __builtin_amdgcn_s_memrealtime());
                     }
                     gbase = p.regions[kRegionHeaderWords + region * H + tid] + excl;
                 } else {
@@ -465,7 +515,9 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
 
         // linear read-back: consecutive threads hold consecutive tile positions, so each digit's
         // keys leave as one contiguous run
-        uint32_t dst[PAIRS ? SLOTS : 1];
+        // key/value: remember each slot's digit (one byte, four to a register) so that the payload's
+        // destination can be rebuilt without keeping SLOTS addresses alive
+        uint32_t dbytes[PAIRS ? (SLOTS + 3) / 4 : 1];
         if (PAIRS) {
 #pragma unroll
             for (int s2 = 0; s2 < SLOTS; s2++) {
@@ -473,8 +525,10 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                 const uint32_t q = round * CAP + slot;
                 const uint32_t k = s_keys[slot];
                 const uint32_t d = digit_at<R>(k, shift);
-                dst[s2] = s_gdelta[d] + q;
-                if (full || q < valid) p.out[dst[s2]] = k;
+                if ((s2 & 3) == 0) dbytes[s2 / 4] = d;
+                else dbytes[s2 / 4] |= d << (8 * (s2 & 3));
+                if (full || q < valid) p.out[s_gdelta[d] + q] = k;
+                if ((s2 & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep at most eight slots in flight
             }
         } else {
             // keys only: sixteen slots at a time, which bounds the registers of the read-back
@@ -497,14 +551,16 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             lds_barrier();   // every key of this round has been read back
 #pragma unroll
             for (int i = 0; i < K; i++) {
-                if (ROUNDS == 1 || (pos[i] / (uint32_t)CAP) == (uint32_t)round) s_keys[pos[i] % (uint32_t)CAP] = val[i];
+                if (ROUNDS == 1 || (pos_at(i) / (uint32_t)CAP) == (uint32_t)round) s_keys[pos_at(i) % (uint32_t)CAP] = val[i];
             }
             lds_barrier();
 #pragma unroll
             for (int s2 = 0; s2 < SLOTS; s2++) {
                 const uint32_t slot = s2 * T + tid;
                 const uint32_t q = round * CAP + slot;
-                if (full || q < valid) p.vals_out[dst[s2]] = s_keys[slot];
+                const uint32_t d = (dbytes[s2 / 4] >> (8 * (s2 & 3))) & 0xFFu;
+                if (full || q < valid) p.vals_out[s_gdelta[d] + q] = s_keys[slot];
+                if ((s2 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
         }
     }

@@ -15,7 +15,7 @@ a = ap.parse_args()
 L = ctypes.CDLL(lsd.LIB_PATH)
 n = 1 << 28
 master = lsd.to_device(mt19937_keys(n, 0) & np.uint32(a.mask))
-stats = torch.zeros((1 << 17) * 10, dtype=torch.int64, device="cuda")
+stats = torch.zeros((1 << 17) * 16, dtype=torch.int64, device="cuda")
 L.lsdsort_debug_set_stats.argtypes = [ctypes.c_void_p]
 L.lsdsort_debug_set_stats(stats.data_ptr())
 names = ["ticket", "keyload", "rank", "scan+pub", "ldswrite", "lookback", "readback+store"]
@@ -30,7 +30,7 @@ for cfg in a.cfgs:
             k = master.clone()
             tm = lsd.GPULSDRadixSortTimed(k, 8, algorithm=algo, workspace=ws)
             assert tm["tiles"] <= (1 << 17)
-            rec = stats.cpu().numpy().astype(np.float64)[: tm["tiles"] * 10].reshape(-1, 10)   # last pass's records
+            rec = stats.cpu().numpy().astype(np.float64)[: tm["tiles"] * 16].reshape(-1, 16)   # last pass's records
             s = np.zeros(16); s[14] = rec[:, 7].mean(); s[13] = rec[:, 8].mean(); tiles = 1
             per = rec[:, :7].mean(axis=0) / 100.0   # us per tile (100 MHz clock)
             rr = rec[rec[:, 9] > 0]
