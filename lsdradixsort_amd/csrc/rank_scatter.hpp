@@ -55,7 +55,7 @@ __device__ __forceinline__ void lds_barrier()
 // tile stamps s_memrealtime (100 MHz) at phase boundaries and adds the differences to
 // a per-tile record p.stats[tile][0..6]; [7] look-back refills, [8] empty polls (thread 0's digit).
 constexpr int kStatsStride = 16;   // [0..6] phases, [7] refills, [8] empty polls, [9] start, [10] rows walked,
-                                   // [11] t(prefix stored), [12] t(prefix met), [13] chain pos it was met at, [14] t(walk start)
+                                   // [11] t(prefix stored), [12] t(prefix met), [13] chain pos it was met at, [14] t(walk start), [15] t(first step consumed)
 #ifdef LSD_PHASE_STATS
 #define LSD_SET(idx, v)                                                                     \
     do {                                                                                    \
@@ -95,7 +95,11 @@ struct Lookback {
     static constexpr int H = 1 << R;
     // rows per step, measured on 2^28 keys (tools/ab_bench.sh): 2 -> 0.534, 4 -> 0.551, 8 -> 0.553 ms/pass at
     // 8-bit digits: a step costs a round trip whatever its width, but every row is 1 KiB of status reads
+#ifdef LSD_LB   // experiment builds (make variant / stats DEFS=-DLSD_LB=n)
+    static constexpr int LB = H >= 64 ? LSD_LB : 8;
+#else
     static constexpr int LB = H >= 64 ? 2 : 8;
+#endif
     static constexpr int SLOTS = 1;   // measured: helper slots (2 or 4) buy nothing here, the extra barrier costs a little
     static constexpr int LDS_WORDS = (SLOTS - 1) * LB * H;
 };
@@ -347,17 +351,20 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     const uint32_t* const status_col = CHAINED ? p.status + (size_t)chain_row0 * H + my_digit : nullptr;
     uint32_t window[LB];
     int32_t j = (int32_t)chain_pos - 1;   // nearest predecessor in the chain not yet consumed
+    auto first_step = [&]() {
+        if (CHAINED && my_slot < (uint32_t)LSLOTS) {
+            // first look-back step, consumed after the LDS writes of round 0: slot s covers
+            // predecessors j - s*LB - l, so LSLOTS*LB status rows cost one round trip
+            const int32_t j0 = j - (int32_t)(my_slot * LB);
+#pragma unroll
+            for (int l = 0; l < LB; l++) window[l] = (j0 - l >= 0) ? load_status(status_col + (size_t)(j0 - l) * H) : c_stale;
+        }
+    };
     if (CHAINED && tid < (uint32_t)H) {
-        // publish as early as possible: successors can already add this tile's counts
+        // publish as early as possible: successors can already add this tile's counts (behind the loads
+        // above in issue order, so that their consumer need not outwait this store's acknowledgement)
         const uint32_t code = chain_pos == 0 ? c_prefix : code_aggregate(parity);
         store_status(p.status + (size_t)tile * H + tid, (pub_total << 2) | code);
-    }
-    if (CHAINED && my_slot < (uint32_t)LSLOTS) {
-        // first look-back step, issued now and consumed after the LDS reorder below: slot s covers
-        // predecessors j - s*LB - l, so LSLOTS*LB status rows cost one round trip
-        const int32_t j0 = j - (int32_t)(my_slot * LB);
-#pragma unroll
-        for (int l = 0; l < LB; l++) window[l] = (j0 - l >= 0) ? load_status(status_col + (size_t)(j0 - l) * H) : c_stale;
     }
 
     uint32_t incl = wave_inclusive_scan(tid < (uint32_t)H ? total : 0u, lane);
@@ -427,6 +434,10 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         return i % 2 == 0 ? (w & 0xFFFFu) : (w >> 16);
     };
 
+    // Issued here, not right after publishing: what matters is how fresh the rows are when they are
+    // consumed (a row read early shows counts where a prefix would be by now, and the walk goes on
+    // past it); the LDS writes below are cover enough.  A/B on 2^28 keys: 2.29-2.35 -> 2.22-2.23 ms.
+    first_step();
 #pragma unroll
     for (int round = 0; round < ROUNDS; round++) {
         if (round > 0) lds_barrier();   // the previous round has been read back
@@ -467,7 +478,10 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                             }
                         }
                         j -= consumed;
-                        if (tid == 0) LSD_COUNT(10, consumed);
+                        if (tid == 0) {
+                            LSD_COUNT(10, consumed);
+                            LSD_SET(15, __builtin_amdgcn_s_memrealtime());   // first (prefetched) step consumed
+                        }
                         uint32_t spins = 0;
                         while (!found) {
                             // further steps: LB rows at a time by the owner alone

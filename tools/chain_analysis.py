@@ -11,6 +11,9 @@ for reg in (0, regions // 2):
     start, walk0, met, pub = us(9), us(14), us(12), us(11)
     depth, refills, empty, metpos = r[:, 10], r[:, 7], r[:, 8], r[:, 13].astype(int)
     ks = np.arange(per // 4, 3 * per // 4)
+    first = us(15)
+    rf = refills[ks] > 0
+    print(f"   wait for the prefetched step {np.mean(first[ks]-walk0[ks]):.2f} us; tiles needing refills {rf.mean():.2f}; per refill {np.sum((met[ks]-first[ks])[rf])/max(1,np.sum(refills[ks][rf])):.2f} us; rows from the first step {np.mean(depth[ks]-0):.1f} total")
     print(f"region {reg}: rows walked {depth[ks].mean():.1f}  refills {refills[ks].mean():.2f}  empty polls {empty[ks].mean():.2f}  walk {np.mean(met[ks]-walk0[ks]):.2f} us")
     # frontier when the walk started / ended, by the publishers' own clocks
     fs, fe, lag = [], [], []
