@@ -188,9 +188,11 @@ def main():
     stage_ms = None
     if rank == 0:
         scat, hist, scan, clear, totals = [], [], [], [], []
+        sort_tile_keys = None
         for _ in range(5):
             kv = pool.fresh()
             tm = lsd.GPULSDRadixSortTimed(kv[0], r, d_vals=kv[1], algorithm=algo, workspace=ws)
+            sort_tile_keys = tm["tile_keys"]
             scat += tm["scatter_ms"]
             hist.append(tm["histogram_ms"])
             scan.append(tm["scan_ms"])
@@ -270,7 +272,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": workload, "keys_per_gpu": n, "radix_bits": r, "algorithm": args.algorithm,
-                       "pairs": bool(args.pairs), "tile_keys": lsd.tile_keys(r)},
+                       "pairs": bool(args.pairs), "tile_keys": sort_tile_keys},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "stages_ms": stage_ms, "extra": extra,
         }
         print(json.dumps(line), flush=True)

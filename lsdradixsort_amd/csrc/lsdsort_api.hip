@@ -54,16 +54,22 @@ bool valid_radix(int r) { return r == 1 || r == 2 || r == 4 || r == 8; }
 
 std::atomic<int> g_shape_override[9];   // per radix_bits: 0 = default, k + 1 = compiled shape k forced
 
-// Tile shape of a sort: the compiled default for (radix, keys-only / key-value), unless
-// lsdsort_set_tile_config pinned one.  Key/value tiles carry a payload register per key, so at
-// 8-bit digits their best shape is the one-workgroup-per-CU 1024x32 tile.
-const TileShape* current_shape(int radix_bits, bool pairs = false)
+// Tile shape of a sort: the one lsdsort_set_tile_config pinned, else the compiled default for the
+// job.  The chained form at 8-bit digits runs large inputs on the one-workgroup-per-CU 1024x32 tile
+// (32768 keys: half the status rows per key, 32 instead of 64 tiles in flight per chain; fastest on
+// uniform keys and the most even across key distributions) and small ones on
+// the 16384-key tile, which fills the device sooner.  Everything else -- the staged form and the
+// stage-level entries, whose tables callers index by lsdsort_tile_keys() -- uses shape 0.
+constexpr size_t kLargeSortKeys = (size_t)1 << 23;
+
+const TileShape* current_shape(int radix_bits, bool pairs = false, size_t n = 0, int algorithm = LSDSORT_ALGO_STAGED)
 {
+    (void)pairs;
     const TileShape* shapes = nullptr;
     const int count = lsd::tile_shapes(radix_bits, &shapes);
     if (count == 0) return nullptr;
     int id = g_shape_override[radix_bits].load(std::memory_order_relaxed) - 1;
-    if (id < 0) id = (pairs && radix_bits == 8 && count > 4) ? 4 : 0;
+    if (id < 0) id = (radix_bits == 8 && algorithm == LSDSORT_ALGO_ONESWEEP && n >= kLargeSortKeys && count > 4) ? 4 : 0;
     if (id >= count) id = 0;
     return &shapes[id];
 }
@@ -238,7 +244,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     LSD_TRY(check_device_ready(&dev));
     const int rank_method = resolve_rank_method(dev, radix_bits);
     const bool pairs = d_vals != nullptr;
-    const TileShape* shape = current_shape(radix_bits, pairs);
+    const TileShape* shape = current_shape(radix_bits, pairs, n, algorithm);
     if (!shape) return LSDSORT_ERR_INVALID_ARG;
     const Layout L = make_layout(n, radix_bits, pairs, algorithm, *shape);
     if (!d_ws || (reinterpret_cast<uintptr_t>(d_ws) & (kAlign - 1)) || ws_bytes < L.total) return LSDSORT_ERR_WORKSPACE;
@@ -495,8 +501,11 @@ size_t lsdsort_workspace_bytes_ex(size_t n, int radix_bits, int pairs, int algor
 {
     if (!valid_radix(radix_bits) || n > LSDSORT_MAX_KEYS) return 0;
     if (algorithm != LSDSORT_ALGO_ONESWEEP && algorithm != LSDSORT_ALGO_STAGED) return 0;
-    const TileShape* shape = current_shape(radix_bits, pairs != 0);
-    return make_layout(n, radix_bits, pairs != 0, algorithm, *shape).total;
+    // Sized for the larger of the shapes a sort of up to n keys may pick, so that a workspace made for
+    // n serves every smaller sort as well (the figure is monotonic in n).
+    const size_t a = make_layout(n, radix_bits, pairs != 0, algorithm, *current_shape(radix_bits, pairs != 0, n, algorithm)).total;
+    const size_t b = make_layout(n, radix_bits, pairs != 0, algorithm, *current_shape(radix_bits, pairs != 0, 0, algorithm)).total;
+    return a > b ? a : b;
 }
 
 size_t lsdsort_workspace_bytes(size_t n, int radix_bits, int pairs)

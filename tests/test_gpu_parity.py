@@ -165,6 +165,31 @@ def test_workspace_reuse_and_idempotence(gpu, oracle_mod):
         assert torch.equal(d, before)
 
 
+@pytest.mark.parametrize("n", [(1 << 23) - 1, 1 << 23, (1 << 23) + 12345])
+def test_default_shape_threshold(gpu, oracle_mod, n):
+    """The library switches its default tile (16384 -> 32768 keys at 8-bit digits) at 2^23 keys:
+    both sides of the switch, keys and pairs, against std::sort / std::stable_sort."""
+    keys = oracle_mod.mt19937_keys(n, 11)
+    assert np.array_equal(_sort_dev(gpu, keys, 8), np.sort(keys))
+    vals = np.arange(n, dtype=np.uint32)
+    ek, ev = oracle_mod.std_stable_sort_pairs(keys >> np.uint32(12), vals)
+    k, v = _sort_dev(gpu, keys >> np.uint32(12), 8, 0, vals)
+    assert np.array_equal(k, ek) and np.array_equal(v, ev)
+
+
+def test_workspace_serves_smaller_sorts(gpu, oracle_mod):
+    """A workspace sized for n keys must do for every n' <= n, whichever tile the library picks."""
+    n = (1 << 23) + 5
+    ws = gpu.alloc_workspace(n, 8)
+    for m in (n, (1 << 23) - 7, 1 << 20, 1000, 1):
+        keys = oracle_mod.mt19937_keys(m, m & 0xFF)
+        d = gpu.to_device(keys)
+        gpu.GPULSDRadixSort(d, 8, workspace=ws, check_fault=True)
+        assert np.array_equal(gpu.to_host(d), np.sort(keys)), m
+    sizes = [gpu.lib().lsdsort_workspace_bytes(m, 8, 0) for m in ((1 << 22), (1 << 23) - 1, 1 << 23, (1 << 23) + 1, 1 << 24)]
+    assert sizes == sorted(sizes)
+
+
 def test_device_entry_errors(gpu):
     import torch
 

@@ -6,6 +6,11 @@ import numpy as np, torch
 import lsdradixsort_amd as lsd
 from bench import mt19937_keys
 
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--radix", type=int, nargs="*", default=[8, 4])
+ap.add_argument("--cfg", type=int, default=-1, help="tile configuration for every radix listed (-1: library default)")
+a = ap.parse_args()
 n = 1 << 28
 base = mt19937_keys(n, 0)
 cases = {
@@ -18,7 +23,9 @@ cases = {
     "16_values_per_digit": lambda: base & np.uint32(0x0F0F0F0F),
     "small_range_2^20": lambda: base & np.uint32(0xFFFFF),
 }
-for r in (8, 4):
+for r in a.radix:
+    if a.cfg >= 0:
+        lsd.set_tile_config(r, a.cfg)
     ws = lsd.alloc_workspace(n, r)
     for name, make in cases.items():
         d0 = lsd.to_device(make())
@@ -36,5 +43,5 @@ for r in (8, 4):
         u = d.to(torch.int64) & 0xFFFFFFFF
         ok = bool((u[1:] >= u[:-1]).all())
         lsd.lib().lsdsort_check_device(ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        print(f"r={r} {name:22s} {np.median(times):8.3f} ms  {n / np.median(times) / 1e6:8.1f} Gkeys/s  sorted={ok}", flush=True)
+        print(f"r={r} cfg={a.cfg} {name:22s} {np.median(times):8.3f} ms  {n / np.median(times) / 1e6:8.1f} Gkeys/s  sorted={ok}", flush=True)
         del d0, d, u
