@@ -151,6 +151,14 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     const uint32_t wave = tid >> 6;
     const uint32_t shift = p.shift;
 
+    if (CHAINED && p.status_clear) {
+        // housekeeping for the NEXT pass (it runs in the other status array): the grid's workgroups
+        // share the rows out (one each when the grid is the row count)
+        for (uint32_t row = blockIdx.x; row < p.num_tiles; row += gridDim.x)
+            for (uint32_t i = tid; i < (uint32_t)H; i += (uint32_t)T) p.status_clear[(size_t)row * H + i] = 0;
+    }
+
+
     // wave-private tables start at zero
 #pragma unroll
     for (int j = 0; j < (H + kWave - 1) / kWave; j++) {
@@ -167,11 +175,6 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     uint32_t range_end;        // one past the last key this tile may touch
     uint32_t region = 0;
     uint32_t chain_row0 = 0;
-    if (CHAINED && p.status_clear) {
-        // housekeeping for the NEXT pass (it runs in the other status array): one row per workgroup
-#pragma unroll
-        for (uint32_t i = tid; i < (uint32_t)H; i += (uint32_t)T) p.status_clear[(size_t)blockIdx.x * H + i] = 0;
-    }
     if (CHAINED) {
         // A tile comes from a ticket taken on arrival from its region's dispenser, and it only ever
         // waits on earlier tickets of the SAME dispenser -- workgroups that have already started.
@@ -446,6 +449,17 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             if (ROUNDS == 1 || (pos_at(i) / (uint32_t)CAP) == (uint32_t)round) s_keys[pos_at(i) % (uint32_t)CAP] = key[i];
         }
         if (PAIRS && ROUNDS == 1) load_vals();   // the key registers are free now
+        // One workgroup per CU (the 32768-key tile), keys only: nothing else runs on the CU while this
+        // tile waits for its predecessors, so fetch the tile-ordered keys back from LDS BEFORE the
+        // look-back is consumed and leave only destination lookups and stores behind it (+0.7 %; with
+        // two workgroups per CU the extra barrier costs more than it hides: -1.5 %).
+        constexpr bool PREREAD = !PAIRS && ROUNDS == 1 && TILE >= 32768;
+        uint32_t back[PREREAD ? SLOTS : 1];
+        if (PREREAD) {
+            lds_barrier();   // the whole tile is in LDS
+#pragma unroll
+            for (int s2 = 0; s2 < SLOTS; s2++) back[s2] = s_keys[s2 * T + tid];
+        }
 
         if (round == 0) {
             LSD_STAMP(4);   // first round's LDS writes
@@ -543,6 +557,14 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                 else dbytes[s2 / 4] |= d << (8 * (s2 & 3));
                 if (full || q < valid) p.out[s_gdelta[d] + q] = k;
                 if ((s2 & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep at most eight slots in flight
+            }
+        } else if (PREREAD) {
+#pragma unroll
+            for (int s2 = 0; s2 < SLOTS; s2++) {
+                const uint32_t q = s2 * T + tid;
+                const uint32_t k = back[PREREAD ? s2 : 0];
+                const uint32_t d = digit_at<R>(k, shift);
+                if (full || q < valid) p.out[s_gdelta[d] + q] = k;
             }
         } else {
             // keys only: sixteen slots at a time, which bounds the registers of the read-back
