@@ -244,6 +244,33 @@ def main():
         extra["r4_256M_keys_mkeys_s"] = round(quick(4, False, n), 1)
         extra["pairs_r8_128M_pairs_mpairs_s"] = round(quick(8, True, n // 2), 1)
 
+        # Stage micro-benchmarks: the counterparts of the reference's TestBuildHistogram
+        # (.cu:704) and TestGPUPrefixSum (.cu:304) harnesses, through the stage-level C-ABI entries.
+        def time_stage(fn, reps=5):
+            ts = []
+            for i in range(reps + 1):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                torch.cuda.synchronize()
+                if i:
+                    ts.append(e0.elapsed_time(e1))
+            return float(np.median(ts))
+        hist_ms = time_stage(lambda: lsd.BuildHistograms(master, 8, 0))
+        h = lsd.BuildHistograms(master, 8, 0)
+        offs_ms = time_stage(lambda: lsd.BuildOffsets(h, 8))
+        dh_ms = time_stage(lambda: lsd.DigitHistograms(master, 8))
+        extra["stage_bench"] = {
+            "tile_histograms_r8": {"ms": round(hist_ms, 4), "read_gbs": round(4 * n / hist_ms / 1e6, 1),
+                                   "replaces": "BuildHistogramsKernel .cu:660-702 (TestBuildHistogram .cu:704)"},
+            "tile_offsets_r8": {"ms": round(offs_ms, 4), "tiles": int(h.shape[0]),
+                                "table_gbs": round(3 * 4 * h.numel() / offs_ms / 1e6, 1),
+                                "replaces": "offset construction .cu:862-895 (TestGPUPrefixSum .cu:304)"},
+            "digit_histograms_all_passes_r8": {"ms": round(dh_ms, 4), "read_gbs": round(4 * n / dh_ms / 1e6, 1)},
+        }
+        del h
+
     # ---- CPU baseline: the reference's std::sort path on the host, one thread ----
     cpu_baseline = None
     if rank == 0 and not distributed and not args.no_cpu_baseline:

@@ -198,8 +198,11 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                 // regions (skewed digits leave most of them empty) costs loads, not atomics.
                 const uint32_t region_tiles = p.regions[2 * kMaxRegions + x];
                 if (a > 0 && region_tiles == 0) continue;
-                const uint32_t ticket = atomicAdd(p.tickets + x, 1u);
                 const uint32_t r_start = p.regions[x], r_len = p.regions[kMaxRegions + x], row0 = p.regions[3 * kMaxRegions + x];
+                const uint32_t ticket = atomicAdd(p.tickets + x, 1u);
+                // the extents are needed only by a winning ticket, and the optimiser would sink their loads
+                // behind the comparison: a second dependent round trip (0.5 us) per tile
+                asm volatile("" : : "v"(r_start), "v"(r_len), "v"(row0));
                 if (ticket < region_tiles) {
                     got = x;
                     s_misc[24] = r_start;
@@ -354,7 +357,10 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     const uint32_t* const status_col = CHAINED ? p.status + (size_t)chain_row0 * H + my_digit : nullptr;
     uint32_t window[LB];
     int32_t j = (int32_t)chain_pos - 1;   // nearest predecessor in the chain not yet consumed
+    uint32_t region_base = 0;   // where this region's keys of digit `tid` start in the output
     auto first_step = [&]() {
+        // fetched here rather than where it is used, after the walk: one dependent round trip less
+        if (CHAINED && tid < (uint32_t)H) region_base = p.regions[kRegionHeaderWords + region * H + tid];
         if (CHAINED && my_slot < (uint32_t)LSLOTS) {
             // first look-back step, consumed after the LDS writes of round 0: slot s covers
             // predecessors j - s*LB - l, so LSLOTS*LB status rows cost one round trip
@@ -531,7 +537,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                         store_status(p.status + (size_t)tile * H + tid, ((excl + pub_total) << 2) | c_prefix);
                         if (tid == 0) LSD_SET(11, __builtin_amdgcn_s_memrealtime());
                     }
-                    gbase = p.regions[kRegionHeaderWords + region * H + tid] + excl;
+                    gbase = region_base + excl;
                 } else {
                     gbase = p.global_off[(size_t)tile * H + tid];
                 }

@@ -63,11 +63,13 @@ class ShardResult:
     counts: object          # world x world int64 matrix: counts[src][dst] = keys src sent to dst
 
 
-def distributed_sort(local_keys, backend=None, group=None) -> ShardResult:
+def distributed_sort(local_keys, backend=None, group=None, exchange_always: bool = False) -> ShardResult:
     """Sort the union of every rank's ``local_keys``; returns this rank's slice.
 
     ``local_keys``: int32 tensor of uint32 bit patterns on this rank's device.  Collective:
     every rank of ``group`` must call it.  Result slices concatenate in rank order.
+    ``exchange_always`` runs partition, count exchange and all-to-all even for a world of one
+    (a one-GPU box can then exercise the RCCL calls; the default skips them there).
     """
     import torch
     import torch.distributed as dist
@@ -78,7 +80,7 @@ def distributed_sort(local_keys, backend=None, group=None) -> ShardResult:
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     msb_bits = _log2_exact(world)
 
-    if world == 1:
+    if world == 1 and not (exchange_always and dist.is_initialized()):
         out = local_keys.clone()
         backend.sort_inplace(out)
         n = out.numel()

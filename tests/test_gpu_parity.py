@@ -286,6 +286,34 @@ def test_msb_partition(gpu, oracle_mod, msb_bits):
         assert np.array_equal(gpu.to_host(out), eo), (msb_bits, n)
 
 
+def test_rccl_exchange_path_world_of_one(gpu, oracle_mod):
+    """The multi-GPU driver's collective calls (all_gather_into_tensor of the count matrix,
+    all_to_all_single with split sizes, RCCL = backend "nccl") on the one GPU a test box has:
+    a process group of one rank, exchange forced.  The N > 1 logic is covered by the gloo tests."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from lsdradixsort_amd.dist import HipBackend, distributed_sort
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        keys = oracle_mod.mt19937_keys((1 << 20) + 3, 21)
+        res = distributed_sort(gpu.to_device(keys), backend=HipBackend(8), exchange_always=True)
+        torch.cuda.synchronize()
+        assert res.global_offset == 0 and int(res.counts.sum()) == keys.size
+        assert np.array_equal(gpu.to_host(res.keys), np.sort(keys))
+    finally:
+        dist.destroy_process_group()
+
+
 # ----------------------------------------------------------------------------- full size, by property
 def _as_u64(t):
     import torch
@@ -319,6 +347,33 @@ def test_full_size_properties(gpu, oracle_mod, r):
     gpu.GPULSDRadixSort(again, r, check_fault=True)
     assert torch.equal(again, d), "sorting the sorted array changed it"
     _ = xor_before
+
+
+def test_maximum_size(gpu):
+    """The largest n the library accepts (LSDSORT_MAX_KEYS = 2^30 - 1: 30 value bits per status word),
+    4 GiB of keys (the size of BASELINE configs[3] on ONE GPU): sorted, a permutation (digit
+    histograms and sum unchanged), equal to torch.sort; one key more is refused, not mis-sorted."""
+    import torch
+    from lsdradixsort_amd import errors
+
+    n = (1 << 30) - 1
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(99)
+    d = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda", generator=gen)
+    hist_before = gpu.DigitHistograms(d, 8).clone()
+    sum_before = int(_as_u64(d).sum().item())
+    ws = gpu.alloc_workspace(n, 8)
+    gpu.GPULSDRadixSort(d, 8, workspace=ws, check_fault=True)
+    assert torch.equal(gpu.DigitHistograms(d, 8), hist_before), "not a permutation of the input"
+    step = 1 << 28                                   # compare in slices: int64 views of 2^30 keys are 8 GiB each
+    for lo in range(0, n, step):
+        u = _as_u64(d[lo:min(n, lo + step + 1)])
+        assert bool((u[1:] >= u[:-1]).all()), "not sorted"
+        del u
+    assert sum(int(_as_u64(d[lo:lo + step]).sum().item()) for lo in range(0, n, step)) == sum_before
+    assert gpu.lib().lsdsort_workspace_bytes(n + 1, 8, 0) == 0
+    st = gpu.lib().lsdsort_u32_device(d.data_ptr(), ws.data_ptr(), ws.numel(), n + 1, 8, None)   # refused before any access
+    assert st == errors.LSDSORT_ERR_TOO_LARGE
 
 
 def test_full_size_pairs_properties(gpu):
