@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--algorithm", choices=["onesweep", "staged"], default="onesweep")
     ap.add_argument("--pairs", action="store_true", help="key + uint32 payload (BASELINE configs[4])")
     ap.add_argument("--tile-config", type=int, default=-1)
+    ap.add_argument("--rank-method", type=int, default=-1, help="-1 library default, 0 peer-mask forms, 2 returning LDS add (tuning aid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=26)
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configs reported under 'extra'")
@@ -137,6 +138,8 @@ def main():
     algo = lsd.LSDSORT_ALGO_ONESWEEP if args.algorithm == "onesweep" else lsd.LSDSORT_ALGO_STAGED
     if args.tile_config >= 0:
         lsd.set_tile_config(r, args.tile_config)
+    if args.rank_method >= 0:
+        lsd.set_rank_method(args.rank_method)
     n = 1 << args.log2_keys
     passes = 32 // r
 

@@ -673,19 +673,19 @@ hipError_t probe_lds_add_lane_order(bool* ok, hipStream_t stream)
 // ------------------------------------------------------------------------------------------
 hipError_t launch_rank_scatter_r8(int shape_id, int rank_method, bool chained, const PassParams& p, hipStream_t stream);
 hipError_t launch_rank_scatter_r4(int shape_id, int rank_method, bool chained, const PassParams& p, hipStream_t stream);
-hipError_t launch_rank_scatter_small(int radix_bits, int rank_method, bool chained, const PassParams& p, hipStream_t stream);
+hipError_t launch_rank_scatter_small(int radix_bits, int shape_id, int rank_method, bool chained, const PassParams& p, hipStream_t stream);
 
 // Slot 0 is the default; the others stay compiled for tools/tune.py (DESIGN.md has the sweep).
 static const TileShape kShapesR8[] = {{512, 32}, {1024, 16}, {1024, 32}, {512, 16}, {1024, 32}, {256, 16}};
-static const TileShape kShapesR4[] = {{512, 32}, {512, 16}, {256, 16}, {1024, 32}};
-static const TileShape kShapesSmall[] = {{256, 16}};
+static const TileShape kShapesR4[] = {{512, 32}, {512, 16}, {256, 16}, {1024, 32}, {1024, 32}, {1024, 16}};
+static const TileShape kShapesSmall[] = {{256, 16}, {512, 32}, {1024, 32}};
 
 int tile_shapes(int radix_bits, const TileShape** out)
 {
     switch (radix_bits) {
         case 8: *out = kShapesR8; return (int)(sizeof(kShapesR8) / sizeof(TileShape));
         case 4: *out = kShapesR4; return (int)(sizeof(kShapesR4) / sizeof(TileShape));
-        case 1: case 2: case 3: *out = kShapesSmall; return 1;
+        case 1: case 2: case 3: *out = kShapesSmall; return (int)(sizeof(kShapesSmall) / sizeof(TileShape));
         default: *out = nullptr; return 0;
     }
 }
@@ -701,7 +701,7 @@ hipError_t launch_rank_scatter(int radix_bits, const TileShape& shape, int rank_
     switch (radix_bits) {
         case 8: return launch_rank_scatter_r8(id, rank_method, chained, p, stream);
         case 4: return launch_rank_scatter_r4(id, rank_method, chained, p, stream);
-        default: return launch_rank_scatter_small(radix_bits, rank_method, chained, p, stream);
+        default: return launch_rank_scatter_small(radix_bits, id, rank_method, chained, p, stream);
     }
 }
 

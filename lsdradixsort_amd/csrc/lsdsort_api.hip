@@ -55,12 +55,22 @@ bool valid_radix(int r) { return r == 1 || r == 2 || r == 4 || r == 8; }
 std::atomic<int> g_shape_override[9];   // per radix_bits: 0 = default, k + 1 = compiled shape k forced
 
 // Tile shape of a sort: the one lsdsort_set_tile_config pinned, else the compiled default for the
-// job.  The chained form at 8-bit digits runs large inputs on the one-workgroup-per-CU 1024x32 tile
-// (32768 keys: half the status rows per key, 32 instead of 64 tiles in flight per chain; fastest on
-// uniform keys and the most even across key distributions) and small ones on
-// the 16384-key tile, which fills the device sooner.  Everything else -- the staged form and the
-// stage-level entries, whose tables callers index by lsdsort_tile_keys() -- uses shape 0.
+// job.  The chained form runs large inputs on the one-workgroup-per-CU 1024x32 tile (32768 keys: half
+// the status rows per key, 32 instead of 64 tiles in flight per chain; fastest on uniform keys and the
+// most even across key distributions) and small ones on shape 0 (16384 keys at
+// 4- and 8-bit digits, 4096 below), which fills the device sooner.  Everything else -- the staged form
+// and the stage-level entries, whose tables callers index by lsdsort_tile_keys() -- uses shape 0.
 constexpr size_t kLargeSortKeys = (size_t)1 << 23;
+
+int large_sort_shape(int radix_bits)
+{
+    switch (radix_bits) {
+        case 8: return 4;                 // (1024, 32), one reorder round
+        case 4: return 4;
+        case 1: case 2: case 3: return 2;
+        default: return 0;
+    }
+}
 
 const TileShape* current_shape(int radix_bits, bool pairs = false, size_t n = 0, int algorithm = LSDSORT_ALGO_STAGED)
 {
@@ -69,7 +79,7 @@ const TileShape* current_shape(int radix_bits, bool pairs = false, size_t n = 0,
     const int count = lsd::tile_shapes(radix_bits, &shapes);
     if (count == 0) return nullptr;
     int id = g_shape_override[radix_bits].load(std::memory_order_relaxed) - 1;
-    if (id < 0) id = (radix_bits == 8 && algorithm == LSDSORT_ALGO_ONESWEEP && n >= kLargeSortKeys && count > 4) ? 4 : 0;
+    if (id < 0) id = (algorithm == LSDSORT_ALGO_ONESWEEP && n >= kLargeSortKeys) ? large_sort_shape(radix_bits) : 0;
     if (id >= count) id = 0;
     return &shapes[id];
 }
@@ -198,9 +208,10 @@ int resolve_rank_method(int dev, int radix_bits)
     const bool ok = g_device[dev].lds_add_in_lane_order;
     if (setting == 0 || !ok) return radix_bits > 4 ? lsd::kRankLdsOr : lsd::kRankBallot;
     if (setting == 2) return lsd::kRankLdsAdd;
-    // auto: one LDS op per key beats eight ballots or an OR round trip for wide digits; for
-    // narrow digits most lanes collide on a few counters and the ballots are cheaper.
-    return radix_bits > 4 ? lsd::kRankLdsAdd : lsd::kRankBallot;
+    // auto: one LDS op per key beats the ballots (or an OR round trip) from 4-bit digits up -- measured
+    // 0.55 -> 0.47 ms per pass at 4 bits, where the four ballots cost ~28 vector instructions a key;
+    // with 2..8 counters per wave nearly every lane collides and the ballots are level or ahead.
+    return radix_bits >= 4 ? lsd::kRankLdsAdd : lsd::kRankBallot;
 }
 
 struct StageEvents {
@@ -384,6 +395,7 @@ MsbLayout make_msb_layout(size_t n, int msb_bits)
 {
     MsbLayout L;
     const int r = msb_bits ? msb_bits : 1;
+    // sized for the smallest tile a partition of up to n keys may use (most rows)
     const TileShape* shape = current_shape(r);
     const size_t tile = (size_t)shape->tile();
     L.rows = (uint32_t)((n + tile - 1) / tile) + 1u;
@@ -702,7 +714,7 @@ int lsdsort_msb_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size
     }
     if (n) {
         const uint32_t shift = (uint32_t)(32 - msb_bits);
-        const TileShape* shape = current_shape(msb_bits);
+        const TileShape* shape = current_shape(msb_bits, false, n, LSDSORT_ALGO_ONESWEEP);
         LSD_HIP(lsd::launch_digit_histograms(msb_bits, 1, shift, d_in, (uint32_t)n, hist, stream));
         LSD_HIP(lsd::launch_scan_regions(msb_bits, 1, 1, hist, (uint32_t)n, (uint32_t)shape->tile(), 0, table, stream));
         PassParams p{};
@@ -710,7 +722,7 @@ int lsdsort_msb_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size
         p.out = d_out;
         p.n = (uint32_t)n;
         p.shift = shift;
-        p.num_tiles = L.rows;
+        p.num_tiles = (uint32_t)((n + (size_t)shape->tile() - 1) / (size_t)shape->tile()) + 1u;   // <= L.rows
         p.regions = table;
         p.status = reinterpret_cast<uint32_t*>(ws + L.status);
         p.tickets = reinterpret_cast<uint32_t*>(ws + L.tickets);

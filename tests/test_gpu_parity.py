@@ -135,7 +135,7 @@ def test_tile_configs(gpu, oracle_mod):
     vals = np.arange(keys.size, dtype=np.uint32)
     ek, ev = oracle_mod.std_stable_sort_pairs(keys, vals)
     try:
-        for r, count in ((8, 6), (4, 4)):
+        for r, count in ((8, 6), (4, 6)):
             for cfg in range(count):
                 gpu.set_tile_config(r, cfg)
                 for algo in ALGOS.values():
