@@ -109,7 +109,8 @@ typedef struct lsdsort_timing {
     float clear_ms;       /* workspace control words + tile-status memset                   */
     float histogram_ms;   /* stage 1 (onesweep: all digits in one read; staged: summed)     */
     float scan_ms;        /* stage 2 (digit-count scan / tile offset tables)                */
-    float scatter_ms[LSDSORT_MAX_PASSES]; /* stage 3, one entry per pass                    */
+    float scatter_ms[LSDSORT_MAX_PASSES]; /* stage 3, one entry per pass (chained form: the  */
+                                          /* kernel's own begin/end, hipExtLaunchKernel)    */
     int passes;
     int tile_keys;        /* keys per rank-and-scatter tile                                 */
     int tiles;

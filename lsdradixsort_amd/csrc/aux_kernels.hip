@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
 #define LSD_R4_HIST_THREADS 512
 #endif
 #ifndef LSD_R8_HIST_THREADS
-#define LSD_R8_HIST_THREADS 1024
+#define LSD_R8_HIST_THREADS 512
 #endif
 
 template <int R, int THREADS, bool WIDE = false>
@@ -348,7 +348,7 @@ hipError_t launch_joint_histograms(int radix_bits, const uint32_t* keys, uint32_
 #else
         case 4: return launch_joint_inst<4, LSD_R4_HIST_THREADS, true>(keys, n, region0_keys, joint, stream);   // 64 KiB of counters per workgroup
 #endif
-        case 8: return launch_joint_inst<8, (LSD_R8_REGION_BITS == 3 ? 256 : LSD_R8_HIST_THREADS)>(keys, n, region0_keys, joint, stream);   // 32 KiB of counters per workgroup at 3 bits
+        case 8: return launch_joint_inst<8, (LSD_R8_REGION_BITS == 3 ? 256 : LSD_R8_HIST_THREADS)>(keys, n, region0_keys, joint, stream);   // 32 / 64 / 128 KiB of counters per workgroup at 3 / 4 / 5 bits
         default: return hipErrorInvalidValue;
     }
 }

@@ -31,11 +31,13 @@ int tile_shapes(int radix_bits, const TileShape** out);
 //                the array because pass p-1 just sorted on that digit; its histogram of digit p
 //                is a joint count of two key fields, so it is permutation-invariant and comes
 //                out of the same single upfront read as the plain digit histograms.
-// 8-bit digits: 8 regions (top three bits of the previous digit, one per XCD).  16 and 32 were
-// measured too: the look-back wait falls (4.4 -> 2.7 us per tile at 32) but the upfront joint
-// histogram grows with the table (32 KiB -> 128 KiB of LDS counters per workgroup: 0.36 -> 0.65 ms),
-// a net loss.  4-bit digits: 16 regions (the whole previous digit; the table stays tiny).  Narrower
-// digits and the multi-GPU partition: one region, i.e. one chain.
+// 8-bit digits: 8 regions (top three bits of the previous digit, one per XCD).  16 regions (64 KiB of
+// LDS counters per workgroup in the upfront histogram, which is as fast as with 8: it is bound by the
+// number of LDS atomics, not by the table) sort uniform keys 1 % faster -- whole-sort A/B at 2^28 keys:
+// 8 regions 2.181 ms, 16 regions 2.160 ms, 32 regions 2.205 ms -- but lose 10 % on sorted, reversed and
+// few-valued inputs (104 -> 93 Gkeys/s sorted, 95 -> 84 with 16 values per digit), so 8 stays
+// (-DLSD_R8_REGION_BITS=4 builds the other).  4-bit digits: 16 regions (the whole previous digit).
+// Narrower digits and the multi-GPU partition: one region, i.e. one chain.
 constexpr int kMaxRegions = 32;
 constexpr int kXcds = 8;
 #ifndef LSD_R8_REGION_BITS
@@ -46,6 +48,11 @@ inline constexpr int regions_for_radix(int radix_bits) { return 1 << region_bits
 // Per-pass region table, uint32 words: start[32] | len[32] | tiles[32] | tile_off[32] | base[regions][2^R]
 constexpr int kRegionHeaderWords = 4 * kMaxRegions;
 inline constexpr size_t region_table_words(int radix_bits) { return kRegionHeaderWords + (size_t)kMaxRegions * ((size_t)1 << radix_bits); }
+
+// Set (per host thread) around a rank-and-scatter launch by lsdsort_u32_device_timed: events that
+// receive the kernel's own begin and end timestamps (hipExtLaunchKernelGGL).
+inline thread_local hipEvent_t t_launch_start = nullptr;
+inline thread_local hipEvent_t t_launch_stop = nullptr;
 
 // Everything one rank-and-scatter launch needs.
 struct PassParams {

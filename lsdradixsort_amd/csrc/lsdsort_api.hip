@@ -216,9 +216,23 @@ int resolve_rank_method(int dev, int radix_bits)
 
 struct StageEvents {
     hipEvent_t ev[3 * LSDSORT_MAX_PASSES + 4];
+    hipEvent_t kernel_ev[2 * LSDSORT_MAX_PASSES];   // begin/end of each pass's rank-and-scatter kernel
+    int kernel_count = 0;
     int count = 0;
     bool enabled = false;
     hipStream_t stream = nullptr;
+    int arm_kernel_events()   // the next rank-and-scatter launch of this thread reports into a fresh pair
+    {
+        if (!enabled || kernel_count + 2 > 2 * LSDSORT_MAX_PASSES) return LSDSORT_OK;
+        LSD_HIP(hipEventCreate(&kernel_ev[kernel_count]));
+        kernel_count++;
+        LSD_HIP(hipEventCreate(&kernel_ev[kernel_count]));
+        kernel_count++;
+        lsd::t_launch_start = kernel_ev[kernel_count - 2];
+        lsd::t_launch_stop = kernel_ev[kernel_count - 1];
+        return LSDSORT_OK;
+    }
+    static void disarm_kernel_events() { lsd::t_launch_start = lsd::t_launch_stop = nullptr; }
     int mark()
     {
         if (!enabled) return LSDSORT_OK;
@@ -229,8 +243,10 @@ struct StageEvents {
     }
     void destroy()
     {
+        disarm_kernel_events();
         for (int i = 0; i < count; i++) (void)hipEventDestroy(ev[i]);
-        count = 0;
+        for (int i = 0; i < kernel_count; i++) (void)hipEventDestroy(kernel_ev[i]);
+        count = kernel_count = 0;
     }
 };
 
@@ -241,7 +257,7 @@ struct StageEvents {
     } while (0)
 
 // The pass loop.  Marks (when timing), onesweep: 0 start | 1 after clear | 2 after stage 1 |
-// 3 after stage 2 | 4+p after pass p.  Staged: 0 start | 1 after clear | 2, 3 (empty) | then per
+// 3 after stage 2 | 4 after the last pass.  Staged: 0 start | 1 after clear | 2, 3 (empty) | then per
 // pass three marks: after its histogram, after its offset scan, after its scatter.
 int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, size_t n, int radix_bits,
              int algorithm, hipStream_t stream, StageEvents* ev, lsdsort_timing* timing)
@@ -322,7 +338,10 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             p.status_clear = pass + 1 < passes ? reinterpret_cast<uint32_t*>(ws + ((pass & 1) ? L.status : L.status_odd)) : nullptr;
             p.tickets = reinterpret_cast<uint32_t*>(ws + L.tickets) + (size_t)pass * lsd::kMaxRegions;
             p.parity = 0;
-            LSD_HIP(lsd::launch_rank_scatter(radix_bits, *shape, rank_method, true, p, stream));
+            if (ev) LSD_TRY(ev->arm_kernel_events());
+            const hipError_t launched = lsd::launch_rank_scatter(radix_bits, *shape, rank_method, true, p, stream);
+            StageEvents::disarm_kernel_events();
+            LSD_HIP(launched);
         } else {
             uint32_t* tile_hist = reinterpret_cast<uint32_t*>(ws + L.tile_hist);
             uint32_t* tile_global = reinterpret_cast<uint32_t*>(ws + L.tile_global);
@@ -336,7 +355,10 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             p.global_off = tile_global;
             LSD_HIP(lsd::launch_rank_scatter(radix_bits, *shape, rank_method, false, p, stream));
         }
-        if (ev) LSD_TRY(ev->mark());
+        // Chained form: the passes are launched back to back and only the last one is followed by a
+        // mark -- an event record between two dependent kernels costs ~20 us of queue bubble, which is
+        // not the kernel's time (rocprofv3's kernel trace would disagree by 5 %).
+        if (ev && (algorithm != LSDSORT_ALGO_ONESWEEP || pass + 1 == passes)) LSD_TRY(ev->mark());
         uint32_t* t = src; src = dst; dst = t;
         t = vsrc; vsrc = vdst; vdst = t;
     }
@@ -571,8 +593,9 @@ int lsdsort_u32_device_timed(uint32_t* d_keys, uint32_t* d_vals, void* d_workspa
             LSD_HIP(hipEventElapsedTime(&out->histogram_ms, ev.ev[1], ev.ev[2]));
             LSD_HIP(hipEventElapsedTime(&out->scan_ms, ev.ev[2], ev.ev[3]));
             if (algorithm == LSDSORT_ALGO_ONESWEEP) {
-                for (int p = 0; p + 4 < ev.count && p < LSDSORT_MAX_PASSES; p++)
-                    LSD_HIP(hipEventElapsedTime(&out->scatter_ms[p], ev.ev[3 + p], ev.ev[4 + p]));
+                // marks: 3 = before the first pass, 4 = after the last; per pass: the kernel's own events
+                for (int p = 0; p < out->passes && p < LSDSORT_MAX_PASSES && 2 * p + 1 < ev.kernel_count; p++)
+                    LSD_HIP(hipEventElapsedTime(&out->scatter_ms[p], ev.kernel_ev[2 * p], ev.kernel_ev[2 * p + 1]));
             } else {
                 out->histogram_ms = 0.f;
                 out->scan_ms = 0.f;

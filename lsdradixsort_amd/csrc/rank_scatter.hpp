@@ -41,6 +41,7 @@
 #include "lsd_device.hpp"
 #include "lsd_kernels.hpp"
 #include <cstdio>
+#include <hip/hip_ext.h>
 
 namespace lsd {
 
@@ -636,7 +637,13 @@ hipError_t launch_rank_scatter_inst(const PassParams& p, hipStream_t stream)
     }
 #endif
     const uint32_t grid = p.num_tiles;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(T), lds_bytes, stream, p);
+    if (t_launch_start && t_launch_stop) {
+        // timed sorts: the events take the kernel's own begin and end (no marker packets between the
+        // passes, whose queue bubbles would be counted as kernel time)
+        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(T), (uint32_t)lds_bytes, stream, t_launch_start, t_launch_stop, 0u, p);
+    } else {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(T), lds_bytes, stream, p);
+    }
     return hipGetLastError();
 }
 
