@@ -40,8 +40,10 @@ for r in a.radix:
             torch.cuda.synchronize()
             if i:
                 times.append(e0.elapsed_time(e1))
+        tm = lsd.GPULSDRadixSortTimed(d0.clone(), r, workspace=ws)
+        stages = f"hist {tm['histogram_ms']:.3f} passes " + " ".join(f"{x:.3f}" for x in tm["scatter_ms"])
         u = d.to(torch.int64) & 0xFFFFFFFF
         ok = bool((u[1:] >= u[:-1]).all())
         lsd.lib().lsdsort_check_device(ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        print(f"r={r} cfg={a.cfg} {name:22s} {np.median(times):8.3f} ms  {n / np.median(times) / 1e6:8.1f} Gkeys/s  sorted={ok}", flush=True)
+        print(f"r={r} cfg={a.cfg} {name:22s} {np.median(times):8.3f} ms  {n / np.median(times) / 1e6:8.1f} Gkeys/s  sorted={ok}  | {stages}", flush=True)
         del d0, d, u
