@@ -77,7 +77,9 @@ LSDSORT_API int lsdsort_pairs_u32(uint32_t* keys, uint32_t* vals, size_t n);
 
 /* Bytes of device workspace the device entries need for (n, radix_bits, pairs?, algorithm).
  * Replaces the reference's d_b + d_h + d_block_sums sizing, .cu:919-930 and
- * GetGPUPrefixSumBlockSumsCount .cu:265-276.  Returns 0 for invalid arguments. */
+ * GetGPUPrefixSumBlockSumsCount .cu:265-276.  Returns 0 for invalid arguments.  The figure is
+ * monotonic in n and covers every tile shape the library may pick for up to n keys: a workspace
+ * made for n serves every smaller sort with the same (radix_bits, pairs, algorithm). */
 LSDSORT_API size_t lsdsort_workspace_bytes(size_t n, int radix_bits, int pairs);
 LSDSORT_API size_t lsdsort_workspace_bytes_ex(size_t n, int radix_bits, int pairs, int algorithm);
 
@@ -124,7 +126,9 @@ LSDSORT_API int lsdsort_u32_device_timed(uint32_t* d_keys, uint32_t* d_vals, voi
  * scan micro-benchmarks (counterparts of TestBuildHistogram .cu:704 and TestGPUPrefixSum
  * .cu:304).  Tables are block-major [tiles][2^radix_bits] exactly like the reference's `h`. */
 
-/* Keys per tile of the stage entries for this radix (the reference's `block`). */
+/* Keys per tile of the stage entries for this radix (the reference's `block`).  Whole sorts may
+ * use a larger tile for large n (lsdsort_timing.tile_keys reports it); the stage entries and the
+ * staged algorithm always use this one. */
 LSDSORT_API size_t lsdsort_tile_keys(int radix_bits);
 
 /* Replaces BuildHistogramsKernel, .cu:660-702 (launch .cu:850): d_hist[t][d] = number of
@@ -180,7 +184,7 @@ LSDSORT_API int lsdsort_prepare_device(void);
  *   2  one returning LDS add per key, which needs the LDS to serve the colliding lanes of one
  *      wave instruction in lane order; the library verifies that on the device (a probe
  *      kernel at set-up) and silently uses form 0 if it does not hold;
- *  -1  (default) form 2 for 8-bit digits when the probe passes, form 0 otherwise.
+ *  -1  (default) form 2 for 4- and 8-bit digits when the probe passes, form 0 otherwise.
  * lsdsort_rank_method reports the form a sort with this radix will use on the current device. */
 LSDSORT_API int lsdsort_set_rank_method(int method);
 LSDSORT_API int lsdsort_rank_method(int radix_bits);
