@@ -190,6 +190,37 @@ def test_workspace_serves_smaller_sorts(gpu, oracle_mod):
     assert sizes == sorted(sizes)
 
 
+@pytest.mark.parametrize("r,pairs", [(8, False), (4, False), (8, True)])
+def test_hip_graph_capture_and_replay(gpu, oracle_mod, r, pairs):
+    """The device entry allocates nothing and never synchronises, so a sort can be captured into a HIP
+    graph once and replayed on new data in the same buffers (include/lsdsort.h)."""
+    import torch
+
+    n = (1 << 18) + 77
+    gpu.lib().lsdsort_prepare_device()
+    ws = gpu.alloc_workspace(n, r, pairs)
+    static_k = gpu.to_device(oracle_mod.mt19937_keys(n, 1))
+    static_v = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
+    gpu.GPULSDRadixSort(static_k, r, d_vals=static_v, workspace=ws)       # warm-up outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        gpu.GPULSDRadixSort(static_k, r, d_vals=static_v, workspace=ws)
+    for seed in (2, 3):
+        keys = oracle_mod.mt19937_keys(n, seed) >> np.uint32(8 if pairs else 0)
+        static_k.copy_(gpu.to_device(keys))
+        if pairs:
+            static_v.copy_(torch.arange(n, dtype=torch.int32, device="cuda"))
+        graph.replay()
+        torch.cuda.synchronize()
+        if pairs:
+            ek, ev = oracle_mod.std_stable_sort_pairs(keys, np.arange(n, dtype=np.uint32))
+            assert np.array_equal(gpu.to_host(static_k), ek) and np.array_equal(gpu.to_host(static_v), ev), seed
+        else:
+            assert np.array_equal(gpu.to_host(static_k), np.sort(keys)), seed
+    assert gpu.lib().lsdsort_check_device(ws.data_ptr(), None) == 0
+
+
 def test_device_entry_errors(gpu):
     import torch
 

@@ -11,6 +11,7 @@ ap.add_argument("--cfgs", type=int, nargs="*", default=[0])
 ap.add_argument("--chunk", type=int, nargs="*", default=[0, 16])
 ap.add_argument("--algos", type=int, nargs="*", default=[0, 1])
 ap.add_argument("--mask", type=lambda x: int(x, 0), default=0xFFFFFFFF)
+ap.add_argument("--radix", type=int, default=8)
 a = ap.parse_args()
 L = ctypes.CDLL(lsd.LIB_PATH)
 n = 1 << 28
@@ -20,15 +21,15 @@ L.lsdsort_debug_set_stats.argtypes = [ctypes.c_void_p]
 L.lsdsort_debug_set_stats(stats.data_ptr())
 names = ["ticket", "keyload", "rank", "scan+pub", "ldswrite", "lookback", "readback+store"]
 for cfg in a.cfgs:
-    lsd.set_tile_config(8, cfg)
+    lsd.set_tile_config(a.radix, cfg)
     for algo in a.algos:
         for C in a.chunk:
             lsd.set_xcd_chunk(C)
-            ws = lsd.alloc_workspace(n, 8, False, algo)
-            k = master.clone(); lsd.GPULSDRadixSort(k, 8, algorithm=algo, workspace=ws); torch.cuda.synchronize()
+            ws = lsd.alloc_workspace(n, a.radix, False, algo)
+            k = master.clone(); lsd.GPULSDRadixSort(k, a.radix, algorithm=algo, workspace=ws); torch.cuda.synchronize()
             stats.zero_(); torch.cuda.synchronize()
             k = master.clone()
-            tm = lsd.GPULSDRadixSortTimed(k, 8, algorithm=algo, workspace=ws)
+            tm = lsd.GPULSDRadixSortTimed(k, a.radix, algorithm=algo, workspace=ws)
             assert tm["tiles"] <= (1 << 17)
             rec = stats.cpu().numpy().astype(np.float64)[: tm["tiles"] * 16].reshape(-1, 16)   # last pass's records
             s = np.zeros(16); s[14] = rec[:, 7].mean(); s[13] = rec[:, 8].mean(); tiles = 1
