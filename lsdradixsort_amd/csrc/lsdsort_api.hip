@@ -55,21 +55,29 @@ bool valid_radix(int r) { return r == 1 || r == 2 || r == 4 || r == 8; }
 std::atomic<int> g_shape_override[9];   // per radix_bits: 0 = default, k + 1 = compiled shape k forced
 
 // Tile shape of a sort: the one lsdsort_set_tile_config pinned, else the compiled default for the
-// job.  The chained form runs large inputs on the one-workgroup-per-CU 1024x32 tile (32768 keys: half
-// the status rows per key, 32 instead of 64 tiles in flight per chain; fastest on uniform keys and the
-// most even across key distributions) and small ones on shape 0 (16384 keys at
-// 4- and 8-bit digits, 4096 below), which fills the device sooner.  Everything else -- the staged form
-// and the stage-level entries, whose tables callers index by lsdsort_tile_keys() -- uses shape 0.
-constexpr size_t kLargeSortKeys = (size_t)1 << 23;
+// job.  The chained form picks by size (tools/size_sweep.py, shape ids of aux_kernels.hip):
+//   n >= 2^23 : the one-workgroup-per-CU 1024x32 tile (32768 keys: half the status rows per key, 32
+//               instead of 64 tiles in flight per chain; fastest on uniform keys and the most even
+//               across key distributions);
+//   n >= 2^21 : 16384 keys;   n >= 2^19 : 8192 keys;   below : 4096 keys -- small sorts are launch-bound
+//               (seven launches, ~40 us) and need enough tiles to occupy 256 CUs at all.
+// Everything else -- the staged form and the stage-level entries, whose tables callers index by
+// lsdsort_tile_keys() -- uses shape 0.
+struct ShapeClass {
+    size_t below;   // applies to n < below
+    int shape8, shape4, shape_narrow;
+};
+constexpr ShapeClass kShapeClasses[] = {
+    {(size_t)1 << 19, 5, 1, 0},
+    {(size_t)1 << 21, 3, 1, 0},
+    {(size_t)1 << 23, 0, 0, 1},
+    {~(size_t)0, 4, 4, 2},
+};
+constexpr int kNumShapeClasses = (int)(sizeof(kShapeClasses) / sizeof(kShapeClasses[0]));
 
-int large_sort_shape(int radix_bits)
+int class_shape(const ShapeClass& c, int radix_bits)
 {
-    switch (radix_bits) {
-        case 8: return 4;                 // (1024, 32), one reorder round
-        case 4: return 4;
-        case 1: case 2: case 3: return 2;
-        default: return 0;
-    }
+    return radix_bits == 8 ? c.shape8 : (radix_bits == 4 ? c.shape4 : c.shape_narrow);
 }
 
 const TileShape* current_shape(int radix_bits, bool pairs = false, size_t n = 0, int algorithm = LSDSORT_ALGO_STAGED)
@@ -79,7 +87,16 @@ const TileShape* current_shape(int radix_bits, bool pairs = false, size_t n = 0,
     const int count = lsd::tile_shapes(radix_bits, &shapes);
     if (count == 0) return nullptr;
     int id = g_shape_override[radix_bits].load(std::memory_order_relaxed) - 1;
-    if (id < 0) id = (algorithm == LSDSORT_ALGO_ONESWEEP && n >= kLargeSortKeys) ? large_sort_shape(radix_bits) : 0;
+    if (id < 0) {
+        id = 0;
+        if (algorithm == LSDSORT_ALGO_ONESWEEP && n > 0) {
+            for (int c = 0; c < kNumShapeClasses; c++)
+                if (n < kShapeClasses[c].below) {
+                    id = class_shape(kShapeClasses[c], radix_bits);
+                    break;
+                }
+        }
+    }
     if (id >= count) id = 0;
     return &shapes[id];
 }
@@ -535,11 +552,20 @@ size_t lsdsort_workspace_bytes_ex(size_t n, int radix_bits, int pairs, int algor
 {
     if (!valid_radix(radix_bits) || n > LSDSORT_MAX_KEYS) return 0;
     if (algorithm != LSDSORT_ALGO_ONESWEEP && algorithm != LSDSORT_ALGO_STAGED) return 0;
-    // Sized for the larger of the shapes a sort of up to n keys may pick, so that a workspace made for
-    // n serves every smaller sort as well (the figure is monotonic in n).
-    const size_t a = make_layout(n, radix_bits, pairs != 0, algorithm, *current_shape(radix_bits, pairs != 0, n, algorithm)).total;
-    const size_t b = make_layout(n, radix_bits, pairs != 0, algorithm, *current_shape(radix_bits, pairs != 0, 0, algorithm)).total;
-    return a > b ? a : b;
+    // Sized for every shape a sort of up to n keys may pick -- its own size class, and each smaller
+    // class at that class's largest n (smaller tiles mean more status rows per key) -- so that a
+    // workspace made for n serves every smaller sort as well; each term, hence the figure, is
+    // monotonic in n.
+    size_t need = make_layout(n, radix_bits, pairs != 0, algorithm, *current_shape(radix_bits, pairs != 0, n, algorithm)).total;
+    if (algorithm == LSDSORT_ALGO_ONESWEEP) {
+        for (int c = 0; c < kNumShapeClasses && kShapeClasses[c].below <= n; c++) {
+            const size_t m = kShapeClasses[c].below - 1;
+            const size_t t = make_layout(m, radix_bits, pairs != 0, algorithm, *current_shape(radix_bits, pairs != 0, m, algorithm)).total;
+            if (t > need) need = t;
+        }
+    }
+    const size_t stage = make_layout(n, radix_bits, pairs != 0, algorithm, *current_shape(radix_bits, pairs != 0, 0, algorithm)).total;
+    return need > stage ? need : stage;
 }
 
 size_t lsdsort_workspace_bytes(size_t n, int radix_bits, int pairs)

@@ -165,12 +165,14 @@ def test_workspace_reuse_and_idempotence(gpu, oracle_mod):
         assert torch.equal(d, before)
 
 
-@pytest.mark.parametrize("n", [(1 << 23) - 1, 1 << 23, (1 << 23) + 12345])
+@pytest.mark.parametrize("n", [(1 << 19) - 1, 1 << 19, (1 << 21) - 1, 1 << 21, (1 << 23) - 1, 1 << 23, (1 << 23) + 12345])
 def test_default_shape_threshold(gpu, oracle_mod, n):
-    """The library switches its default tile (16384 -> 32768 keys at 8-bit digits) at 2^23 keys:
-    both sides of the switch, keys and pairs, against std::sort / std::stable_sort."""
+    """The library picks its tile by size class (4096 / 8192 / 16384 / 32768 keys, switching at 2^19,
+    2^21 and 2^23 keys): both sides of every switch, keys (r = 8 and 4) and pairs, against std::sort /
+    std::stable_sort."""
     keys = oracle_mod.mt19937_keys(n, 11)
     assert np.array_equal(_sort_dev(gpu, keys, 8), np.sort(keys))
+    assert np.array_equal(_sort_dev(gpu, keys, 4), np.sort(keys))
     vals = np.arange(n, dtype=np.uint32)
     ek, ev = oracle_mod.std_stable_sort_pairs(keys >> np.uint32(12), vals)
     k, v = _sort_dev(gpu, keys >> np.uint32(12), 8, 0, vals)
@@ -181,13 +183,16 @@ def test_workspace_serves_smaller_sorts(gpu, oracle_mod):
     """A workspace sized for n keys must do for every n' <= n, whichever tile the library picks."""
     n = (1 << 23) + 5
     ws = gpu.alloc_workspace(n, 8)
-    for m in (n, (1 << 23) - 7, 1 << 20, 1000, 1):
+    for m in (n, (1 << 23) - 7, (1 << 21) + 3, (1 << 21) - 1, (1 << 19) + 1, (1 << 19) - 1, 1000, 1):
         keys = oracle_mod.mt19937_keys(m, m & 0xFF)
         d = gpu.to_device(keys)
         gpu.GPULSDRadixSort(d, 8, workspace=ws, check_fault=True)
         assert np.array_equal(gpu.to_host(d), np.sort(keys)), m
-    sizes = [gpu.lib().lsdsort_workspace_bytes(m, 8, 0) for m in ((1 << 22), (1 << 23) - 1, 1 << 23, (1 << 23) + 1, 1 << 24)]
-    assert sizes == sorted(sizes)
+    points = [1, 4095, 4097, (1 << 19) - 1, 1 << 19, (1 << 19) + 1, (1 << 21) - 1, 1 << 21, (1 << 22), (1 << 23) - 1, 1 << 23,
+              (1 << 23) + 1, 1 << 24]
+    for r, pairs in ((8, 0), (8, 1), (4, 0), (2, 0)):
+        sizes = [gpu.lib().lsdsort_workspace_bytes(m, r, pairs) for m in points]
+        assert sizes == sorted(sizes), (r, pairs)
 
 
 @pytest.mark.parametrize("r,pairs", [(8, False), (4, False), (8, True)])
