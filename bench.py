@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument("--algorithm", choices=["onesweep", "staged"], default="onesweep")
     ap.add_argument("--pairs", action="store_true", help="key + uint32 payload (BASELINE configs[4])")
     ap.add_argument("--tile-config", type=int, default=-1)
+    ap.add_argument("--exercise-exchange", action="store_true",
+                    help="one GPU only: run the sharded path (partition, RCCL count exchange and all-to-all, local sort) with a "
+                         "process group of one rank -- a rehearsal of the N > 1 code on a one-GPU box, not a benchmark")
     ap.add_argument("--rank-method", type=int, default=-1, help="-1 library default, 0 peer-mask forms, 2 returning LDS add (tuning aid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=26)
@@ -127,11 +130,19 @@ def main():
 
     assert lsd.lib().lsdsort_device_count() >= 1, "liblsdsort.so sees no gfx950 device (no CPU fallback)"
 
-    distributed = world > 1
+    distributed = world > 1 or args.exercise_exchange
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     r = args.radix_bits
@@ -165,13 +176,25 @@ def main():
         backend = HipBackend(r)
 
         def run_step(kv):
-            distributed_sort(kv[0], backend=backend)
+            distributed_sort(kv[0], backend=backend, exchange_always=args.exercise_exchange)
 
     elapsed = timed_steps(run_step, pool, args.steps, args.warmup, sync)
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # correctness guard for the sharded path (untimed, collective): every rank's slice is sorted, lies
+        # in its own MSB bucket, and the slices add up to every key
+        res = distributed_sort(pool.fresh()[0], backend=backend, exchange_always=args.exercise_exchange)
+        u = res.keys.to(torch.int64) & 0xFFFFFFFF
+        bits = world.bit_length() - 1
+        ok = bool((u[1:] >= u[:-1]).all()) if u.numel() > 1 else True
+        if u.numel() and bits:
+            ok = ok and int(u[0].item()) >> (32 - bits) == rank and int(u[-1].item()) >> (32 - bits) == rank
+        cnt = torch.tensor([u.numel(), 0 if ok else 1], dtype=torch.int64, device="cuda")
+        dist.all_reduce(cnt)
+        assert int(cnt[0].item()) == n * world and int(cnt[1].item()) == 0, "sharded sort failed its check"
+        del res, u
     check_status = lsd.lib().lsdsort_check_device(ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert check_status == 0, f"device fault word set ({check_status})"
 
