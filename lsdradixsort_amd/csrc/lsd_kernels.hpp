@@ -25,7 +25,8 @@ int tile_shapes(int radix_bits, const TileShape** out);
 // tile ever needs anything from another region.  Each XCD has its own share of the regions:
 // workgroups serve those first (hardware XCC_ID), which keeps neighbouring runs in one L2; and the
 // more chains there are, the fewer tiles are in flight on each, which is what the look-back's
-// waiting time is proportional to (measured: 64 tiles in flight per chain 4.4 us, 32 tiles 2.2 us).
+// walk is proportional to (measured: 64 tiles in flight per chain 7-8 rows and 4.4 us, 32 tiles 3.7
+// rows and 2.2 us).
 //   pass 0     : region x = positions [x*R0, (x+1)*R0), R0 a multiple of the tile size
 //   pass p >= 1: region x = keys whose digit p-1 has top log2(regions) bits x -- contiguous in
 //                the array because pass p-1 just sorted on that digit; its histogram of digit p

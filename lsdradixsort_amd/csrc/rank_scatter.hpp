@@ -24,8 +24,9 @@
 //      at .cu:869).
 //   4. tile base per digit ("global offsets", .cu:885-894):
 //        chained: publish the tile's digit totals, look back over earlier tiles' status words
-//                 (a window of kLookback predecessors per step, loads issued before the LDS
-//                 reorder and consumed after it) until an inclusive prefix is met, publish ours;
+//                 (Lookback::LB rows per step; the first step's loads are issued just before the
+//                 LDS writes of phase 5 and consumed after them) until an inclusive prefix is met,
+//                 publish ours;
 //        staged : read global_off[tile][digit].
 //   5. keys go to LDS at their tile-sorted position (local offset + wave base + rank), are
 //      read back in linear order and stored to  dst = pos - local[d] + global[d]  (.cu:833):
