@@ -61,6 +61,8 @@ def parse_args():
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="one GPU only: run the sharded path (partition, RCCL count exchange and all-to-all, local sort) with a "
                          "process group of one rank -- a rehearsal of the N > 1 code on a one-GPU box, not a benchmark")
+    ap.add_argument("--partition", choices=["msb", "splitters"], default="msb",
+                    help="N > 1: how keys are assigned to ranks (msb: top log2 N bits; splitters: sampled, for skewed keys)")
     ap.add_argument("--rank-method", type=int, default=-1, help="-1 library default, 0 peer-mask forms, 2 returning LDS add (tuning aid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=26)
@@ -176,7 +178,7 @@ def main():
         backend = HipBackend(r)
 
         def run_step(kv):
-            distributed_sort(kv[0], backend=backend, exchange_always=args.exercise_exchange)
+            distributed_sort(kv[0], backend=backend, exchange_always=args.exercise_exchange, partition=args.partition)
 
     elapsed = timed_steps(run_step, pool, args.steps, args.warmup, sync)
     if distributed:
@@ -185,11 +187,11 @@ def main():
         elapsed = float(t.item())
         # correctness guard for the sharded path (untimed, collective): every rank's slice is sorted, lies
         # in its own MSB bucket, and the slices add up to every key
-        res = distributed_sort(pool.fresh()[0], backend=backend, exchange_always=args.exercise_exchange)
+        res = distributed_sort(pool.fresh()[0], backend=backend, exchange_always=args.exercise_exchange, partition=args.partition)
         u = res.keys.to(torch.int64) & 0xFFFFFFFF
         bits = world.bit_length() - 1
         ok = bool((u[1:] >= u[:-1]).all()) if u.numel() > 1 else True
-        if u.numel() and bits:
+        if u.numel() and bits and args.partition == "msb":
             ok = ok and int(u[0].item()) >> (32 - bits) == rank and int(u[-1].item()) >> (32 - bits) == rank
         cnt = torch.tensor([u.numel(), 0 if ok else 1], dtype=torch.int64, device="cuda")
         dist.all_reduce(cnt)

@@ -165,6 +165,15 @@ LSDSORT_API size_t lsdsort_msb_partition_workspace_bytes(size_t n, int msb_bits)
 LSDSORT_API int lsdsort_msb_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size_t n,
                                                  int msb_bits, uint64_t* d_counts, void* d_workspace,
                                                  size_t workspace_bytes, void* hip_stream);
+/* The same partition by value instead of by bit field, for keys that fixed MSB buckets would not
+ * balance: `splitters` is a HOST array of 2^log2_buckets - 1 ascending values (copied into the launch),
+ * bucket(key) = number of splitters <= key, so bucket b holds splitters[b-1] <= key < splitters[b].
+ * Stable; same workspace size as the MSB form (lsdsort_msb_partition_workspace_bytes(n, log2_buckets)).
+ * lsdradixsort_amd/dist.py picks the splitters from a gathered sample. */
+LSDSORT_API int lsdsort_splitter_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size_t n,
+                                                      int log2_buckets, const uint32_t* splitters,
+                                                      uint64_t* d_counts, void* d_workspace,
+                                                      size_t workspace_bytes, void* hip_stream);
 
 /* ---- misc ----------------------------------------------------------------------------- */
 LSDSORT_API const char* lsdsort_strerror(int status);

@@ -57,6 +57,8 @@ SIGNATURES = {
     "lsdsort_msb_partition_workspace_bytes": (c_size, [c_size, c_int]),
     "lsdsort_msb_partition_u32_device": (c_int, [c_u32p, c_u32p, c_size, c_int, ctypes.c_void_p, ctypes.c_void_p,
                                                  c_size, ctypes.c_void_p]),
+    "lsdsort_splitter_partition_u32_device": (c_int, [c_u32p, c_u32p, c_size, c_int, ctypes.POINTER(ctypes.c_uint32),
+                                                      ctypes.c_void_p, ctypes.c_void_p, c_size, ctypes.c_void_p]),
     "lsdsort_strerror": (ctypes.c_char_p, [c_int]),
     "lsdsort_last_hip_error": (c_int, []),
     "lsdsort_last_hip_error_string": (ctypes.c_char_p, []),

@@ -19,7 +19,7 @@ from .errors import LSDSORT_ALGO_ONESWEEP, LSDSORT_ALGO_STAGED, check
 __all__ = [
     "sort", "sort_pairs", "to_device", "to_host", "workspace_bytes", "GPULSDRadixSort",
     "GPULSDRadixSortTimed", "BuildHistograms", "BuildOffsets", "RankScatter", "DigitHistograms",
-    "MSBPartition", "tile_keys", "set_tile_config", "set_rank_method", "rank_method", "set_xcd_chunk", "LSDSORT_ALGO_ONESWEEP", "LSDSORT_ALGO_STAGED",
+    "MSBPartition", "SplitterPartition", "tile_keys", "set_tile_config", "set_rank_method", "rank_method", "set_xcd_chunk", "LSDSORT_ALGO_ONESWEEP", "LSDSORT_ALGO_STAGED",
 ]
 
 
@@ -231,6 +231,29 @@ def MSBPartition(d_keys, msb_bits: int, stream=None):
     check(lib().lsdsort_msb_partition_u32_device(d_keys.data_ptr(), out.data_ptr(), n, msb_bits, counts.data_ptr(),
                                                  ws.data_ptr(), ws.numel(), _stream(stream)),
           "lsdsort_msb_partition_u32_device")
+    if n:
+        check(lib().lsdsort_check_device(ws.data_ptr(), _stream(stream)), "lsdsort_check_device")
+    return out, counts
+
+
+def SplitterPartition(d_keys, splitters, stream=None):
+    """Stable partition by value: bucket(key) = number of ``splitters`` (ascending uint32 values, 1, 3 or 7 of
+    them) <= key -> (partitioned keys, int64 bucket counts).  No splitters: one bucket."""
+    torch = _torch()
+    _dev_i32(d_keys, "d_keys")
+    sp = [int(x) & 0xFFFFFFFF for x in splitters]
+    if len(sp) not in (0, 1, 3, 7):
+        raise ValueError("splitter count must be 0, 1, 3 or 7 (2, 4 or 8 buckets)")
+    bits = (len(sp) + 1).bit_length() - 1
+    n = d_keys.numel()
+    out = torch.empty_like(d_keys)
+    counts = torch.zeros(1 << bits, dtype=torch.int64, device=d_keys.device)
+    ws = torch.empty(max(int(lib().lsdsort_msb_partition_workspace_bytes(n, bits)), 256), dtype=torch.uint8,
+                     device=d_keys.device)
+    arr = (ctypes.c_uint32 * max(len(sp), 1))(*sp)
+    check(lib().lsdsort_splitter_partition_u32_device(d_keys.data_ptr(), out.data_ptr(), n, bits, arr, counts.data_ptr(),
+                                                      ws.data_ptr(), ws.numel(), _stream(stream)),
+          "lsdsort_splitter_partition_u32_device")
     if n:
         check(lib().lsdsort_check_device(ws.data_ptr(), _stream(stream)), "lsdsort_check_device")
     return out, counts

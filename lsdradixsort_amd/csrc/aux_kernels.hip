@@ -102,6 +102,66 @@ static hipError_t launch_digit_histograms_inst(uint32_t shift0, const uint32_t* 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Bucket counts for the splitter partition (multi-GPU step 1 on skewed keys): bucket of a key = the
+// number of (ascending) splitters <= key.  Same structure as the digit histogram above, eight
+// replicated LDS counters per bucket.
+// ------------------------------------------------------------------------------------------
+struct SplitterSet {
+    uint32_t count;
+    uint32_t value[7];
+};
+
+__global__ void __launch_bounds__(kHistThreads) bucket_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                                       SplitterSet sp, uint32_t* __restrict__ hist,
+                                                                       uint32_t vec_chunks)
+{
+    constexpr int C = 8;
+    __shared__ uint32_t s_hist[8 * C];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 8 * C) s_hist[tid] = 0;
+    __syncthreads();
+    auto count_key = [&](uint32_t k) {
+        uint32_t b = 0;
+#pragma unroll
+        for (int i = 0; i < 7; i++) b += (i < (int)sp.count && k >= sp.value[i]) ? 1u : 0u;
+        atomicAdd(&s_hist[b * C + (tid & (C - 1))], 1u);
+    };
+    const uint4* __restrict__ keys4 = reinterpret_cast<const uint4*>(keys);
+    for (uint32_t c = blockIdx.x; c < vec_chunks; c += gridDim.x) {
+        const uint4 v = keys4[(size_t)c * kHistThreads + tid];
+        count_key(v.x);
+        count_key(v.y);
+        count_key(v.z);
+        count_key(v.w);
+    }
+    if (blockIdx.x == 0) {
+        for (uint32_t i = vec_chunks * (kHistThreads * 4) + tid; i < n; i += kHistThreads) count_key(keys[i]);
+    }
+    __syncthreads();
+    if (tid <= sp.count) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int c = 0; c < C; c++) sum += s_hist[tid * C + c];
+        if (sum) atomicAdd(&hist[tid], sum);
+    }
+}
+
+hipError_t launch_bucket_histogram(int bits, const uint32_t* splitters_host, const uint32_t* keys, uint32_t n,
+                                   uint32_t* hist, hipStream_t stream)
+{
+    if (bits < 1 || bits > 3 || !splitters_host) return hipErrorInvalidValue;
+    SplitterSet sp{};
+    sp.count = (1u << bits) - 1u;
+    for (uint32_t i = 0; i < sp.count; i++) sp.value[i] = splitters_host[i];
+    const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
+    const uint32_t vec_chunks = aligned ? n / (kHistThreads * 4) : 0;
+    uint32_t blocks = vec_chunks < 2048 ? vec_chunks : 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(bucket_histogram_kernel, dim3(blocks), dim3(kHistThreads), 0, stream, keys, n, sp, hist, vec_chunks);
+    return hipGetLastError();
+}
+
 hipError_t launch_digit_histograms(int radix_bits, int groups, uint32_t shift0, const uint32_t* keys, uint32_t n,
                                    uint32_t* hist, hipStream_t stream)
 {

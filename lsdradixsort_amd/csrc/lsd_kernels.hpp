@@ -75,6 +75,11 @@ struct PassParams {
     uint32_t* fault;             // workspace fault word
     uint32_t xcd_chunk;          // staged form: consecutive tiles kept on one XCD (0 = no affinity)
     unsigned long long* stats;   // diagnostic builds only (LSD_PHASE_STATS); null otherwise
+    // Splitter partition (narrow-digit kernels only, multi-GPU step 1 for skewed keys): when
+    // num_splitters != 0 it is 2^R - 1 and the "digit" of a key is its bucket, the number of
+    // splitters <= key (ascending splitters); shift is ignored.
+    uint32_t num_splitters;
+    uint32_t splitters[7];
 };
 
 // How stage 3 ranks a key among the same-digit keys of its wave (rank_scatter.hpp).
@@ -94,6 +99,9 @@ hipError_t probe_lds_add_lane_order(bool* ok, hipStream_t stream);
 
 // Stage 1, onesweep: all `groups` digit histograms (digit g at bit shift0 + g*radix_bits) in
 // one read; hist[g][d] must be zero on entry.
+// counts[b] += keys whose bucket (number of ascending splitters <= key) is b; 2^bits buckets, bits <= 3
+hipError_t launch_bucket_histogram(int bits, const uint32_t* splitters_host, const uint32_t* keys, uint32_t n,
+                                   uint32_t* hist, hipStream_t stream);
 hipError_t launch_digit_histograms(int radix_bits, int groups, uint32_t shift0, const uint32_t* keys,
                                    uint32_t n, uint32_t* hist, hipStream_t stream);
 

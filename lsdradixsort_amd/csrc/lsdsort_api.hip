@@ -737,10 +737,15 @@ size_t lsdsort_msb_partition_workspace_bytes(size_t n, int msb_bits)
     return make_msb_layout(n, msb_bits).total;
 }
 
-int lsdsort_msb_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size_t n, int msb_bits,
-                                     uint64_t* d_counts, void* d_workspace, size_t workspace_bytes, void* hip_stream)
+// Stable partition into 2^msb_bits buckets: by the top msb_bits key bits (splitters == nullptr) or by
+// 2^msb_bits - 1 ascending splitters (bucket = number of splitters <= key).
+static int partition_impl(const uint32_t* d_in, uint32_t* d_out, size_t n, int msb_bits, const uint32_t* splitters,
+                          uint64_t* d_counts, void* d_workspace, size_t workspace_bytes, void* hip_stream)
 {
     if (msb_bits < 0 || msb_bits > 3 || !d_counts) return LSDSORT_ERR_INVALID_ARG;
+    if (splitters)
+        for (int i = 1; i < (1 << msb_bits) - 1; i++)
+            if (splitters[i] < splitters[i - 1]) return LSDSORT_ERR_INVALID_ARG;
     if (n > LSDSORT_MAX_KEYS) return LSDSORT_ERR_TOO_LARGE;
     if (n > 0 && (!d_in || !d_out || d_in == d_out)) return LSDSORT_ERR_INVALID_ARG;
     int dev = 0;
@@ -764,7 +769,10 @@ int lsdsort_msb_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size
     if (n) {
         const uint32_t shift = (uint32_t)(32 - msb_bits);
         const TileShape* shape = current_shape(msb_bits, false, n, LSDSORT_ALGO_ONESWEEP);
-        LSD_HIP(lsd::launch_digit_histograms(msb_bits, 1, shift, d_in, (uint32_t)n, hist, stream));
+        if (splitters)
+            LSD_HIP(lsd::launch_bucket_histogram(msb_bits, splitters, d_in, (uint32_t)n, hist, stream));
+        else
+            LSD_HIP(lsd::launch_digit_histograms(msb_bits, 1, shift, d_in, (uint32_t)n, hist, stream));
         LSD_HIP(lsd::launch_scan_regions(msb_bits, 1, 1, hist, (uint32_t)n, (uint32_t)shape->tile(), 0, table, stream));
         PassParams p{};
         p.in = d_in;
@@ -777,10 +785,29 @@ int lsdsort_msb_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size
         p.tickets = reinterpret_cast<uint32_t*>(ws + L.tickets);
         p.parity = 0;
         p.fault = control;
+        if (splitters) {
+            p.num_splitters = (1u << msb_bits) - 1u;
+            for (uint32_t i = 0; i < p.num_splitters; i++) p.splitters[i] = splitters[i];
+        }
         LSD_HIP(lsd::launch_rank_scatter(msb_bits, *shape, resolve_rank_method(dev, msb_bits), true, p, stream));
     }
     LSD_HIP(lsd::launch_widen_counts(hist, d_counts, bins, stream));
     return LSDSORT_OK;
+}
+
+int lsdsort_msb_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size_t n, int msb_bits,
+                                     uint64_t* d_counts, void* d_workspace, size_t workspace_bytes, void* hip_stream)
+{
+    return partition_impl(d_in, d_out, n, msb_bits, nullptr, d_counts, d_workspace, workspace_bytes, hip_stream);
+}
+
+int lsdsort_splitter_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size_t n, int log2_buckets,
+                                          const uint32_t* splitters, uint64_t* d_counts, void* d_workspace,
+                                          size_t workspace_bytes, void* hip_stream)
+{
+    if (log2_buckets > 0 && !splitters) return LSDSORT_ERR_INVALID_ARG;
+    return partition_impl(d_in, d_out, n, log2_buckets, log2_buckets > 0 ? splitters : nullptr, d_counts, d_workspace,
+                          workspace_bytes, hip_stream);
 }
 
 }  // extern "C"

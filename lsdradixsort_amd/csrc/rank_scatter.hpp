@@ -152,6 +152,19 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
     const uint32_t shift = p.shift;
+    // Digit of a key.  The narrow-digit kernels double as the splitter partition (PassParams): there the
+    // digit is the key's bucket.  Wider digits compile to the plain bit-field extract.
+    auto digit_of = [&](uint32_t k) -> uint32_t {
+        if constexpr (R <= 3) {
+            if (p.num_splitters) {   // uniform across the grid
+                uint32_t b = 0;
+#pragma unroll
+                for (int i = 0; i < (1 << R) - 1; i++) b += k >= p.splitters[i] ? 1u : 0u;
+                return b;
+            }
+        }
+        return digit_at<R>(k, shift);
+    };
 
     if (CHAINED && p.status_clear) {
         // housekeeping for the NEXT pass (it runs in the other status array): the grid's workgroups
@@ -288,11 +301,11 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         // serialise on one LDS word although its ranks are simply consecutive.  Only waves whose
         // FIRST row is like that pay for testing every row; uniform random input takes the
         // straight path, where the K atomics issue back to back.
-        const uint32_t d_first = digit_at<R>(key[0], shift);
+        const uint32_t d_first = digit_of(key[0]);
         if (__all(d_first == __builtin_amdgcn_readfirstlane(d_first))) {
 #pragma unroll
             for (int i = 0; i < K; i++) {
-                const uint32_t d = digit_at<R>(key[i], shift);
+                const uint32_t d = digit_of(key[i]);
                 const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
                 if (__all(d == d0)) {
                     const uint32_t before = s_cnt[wave * H + d0];
@@ -306,7 +319,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         } else {
 #pragma unroll
             for (int i = 0; i < K; i++) {
-                const uint32_t d = digit_at<R>(key[i], shift);
+                const uint32_t d = digit_of(key[i]);
                 rank[i] = __hip_atomic_fetch_add((lds_u32*)&s_cnt[wave * H + d], 1u, __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
@@ -315,7 +328,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         const uint64_t lane_bit = 1ull << lane;
 #pragma unroll
         for (int i = 0; i < K; i++) {
-            const uint32_t d = digit_at<R>(key[i], shift);
+            const uint32_t d = digit_of(key[i]);
             uint64_t peers;
             if (RANK == kRankLdsOr) {
                 __hip_atomic_fetch_or((lds_u64*)&s_tab[wave * H + d], lane_bit, __ATOMIC_RELAXED,
@@ -430,7 +443,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         // would cost K registers
         uint32_t kk = key[i];
         asm volatile("" : "+v"(kk));
-        const uint32_t d = digit_at<R>(kk, shift);
+        const uint32_t d = digit_of(kk);
         const uint32_t q = s_cnt[wave * H + d] + rank[i];
         if (!PACKED) pos[i] = q;
         else if (i % 2 == 0) pos[i / 2] = q;
@@ -560,7 +573,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                 const uint32_t slot = s2 * T + tid;
                 const uint32_t q = round * CAP + slot;
                 const uint32_t k = s_keys[slot];
-                const uint32_t d = digit_at<R>(k, shift);
+                const uint32_t d = digit_of(k);
                 if ((s2 & 3) == 0) dbytes[s2 / 4] = d;
                 else dbytes[s2 / 4] |= d << (8 * (s2 & 3));
                 if (full || q < valid) p.out[s_gdelta[d] + q] = k;
@@ -571,7 +584,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             for (int s2 = 0; s2 < SLOTS; s2++) {
                 const uint32_t q = s2 * T + tid;
                 const uint32_t k = back[PREREAD ? s2 : 0];
-                const uint32_t d = digit_at<R>(k, shift);
+                const uint32_t d = digit_of(k);
                 if (full || q < valid) p.out[s_gdelta[d] + q] = k;
             }
         } else {
@@ -584,7 +597,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                     const uint32_t slot = (s0 + u) * T + tid;
                     const uint32_t q = round * CAP + slot;
                     const uint32_t k = s_keys[slot];
-                    const uint32_t d = digit_at<R>(k, shift);
+                    const uint32_t d = digit_of(k);
                     if (full || q < valid) p.out[s_gdelta[d] + q] = k;
                 }
             }

@@ -42,6 +42,9 @@ class HipBackend:
     def msb_partition(self, keys, msb_bits: int):
         return self._api.MSBPartition(keys, msb_bits)
 
+    def splitter_partition(self, keys, splitters):
+        return self._api.SplitterPartition(keys, splitters)
+
     def sort_inplace(self, keys):
         n = keys.numel()
         need = self._api.workspace_bytes(n, self.radix_bits)
@@ -63,13 +66,43 @@ class ShardResult:
     counts: object          # world x world int64 matrix: counts[src][dst] = keys src sent to dst
 
 
-def distributed_sort(local_keys, backend=None, group=None, exchange_always: bool = False) -> ShardResult:
+SAMPLES_PER_RANK = 4096
+
+
+def choose_splitters(local_keys, world: int, group=None, samples: int = SAMPLES_PER_RANK):
+    """world - 1 ascending uint32 splitters, identical on every rank: each rank contributes ``samples``
+    keys taken at a regular stride through its shard (deterministic), the gathered sample is sorted and
+    cut into ``world`` equal parts.  Collective.  With 4096 samples per rank the buckets of an arbitrary
+    key distribution come out within a few per cent of n/world -- except for values that occur more
+    often than that themselves: equal keys cannot be told apart, all of them go to one bucket."""
+    import torch
+    import torch.distributed as dist
+
+    n = local_keys.numel()
+    # a rank with fewer keys than samples repeats some; an empty rank contributes the largest key so
+    # that it does not pull the quantiles down
+    if n:
+        idx = (torch.arange(samples, device=local_keys.device, dtype=torch.int64) * n) // samples
+        mine = local_keys[idx].to(torch.int64) & 0xFFFFFFFF
+    else:
+        mine = torch.full((samples,), 0xFFFFFFFF, dtype=torch.int64, device=local_keys.device)
+    everyone = torch.empty(world * samples, dtype=torch.int64, device=local_keys.device)
+    dist.all_gather_into_tensor(everyone, mine.contiguous(), group=group)
+    ordered = torch.sort(everyone).values.cpu()          # world * 4096 values: host-side work, not the hot path
+    return [int(ordered[(b * ordered.numel()) // world]) for b in range(1, world)]
+
+
+def distributed_sort(local_keys, backend=None, group=None, exchange_always: bool = False,
+                     partition: str = "msb") -> ShardResult:
     """Sort the union of every rank's ``local_keys``; returns this rank's slice.
 
     ``local_keys``: int32 tensor of uint32 bit patterns on this rank's device.  Collective:
     every rank of ``group`` must call it.  Result slices concatenate in rank order.
     ``exchange_always`` runs partition, count exchange and all-to-all even for a world of one
     (a one-GPU box can then exercise the RCCL calls; the default skips them there).
+    ``partition``: "msb" -- rank b owns the keys whose top log2(world) bits are b (balanced for
+    uniform keys, no extra step); "splitters" -- rank b owns [splitter[b-1], splitter[b]) with
+    splitters drawn from a gathered sample (``choose_splitters``): balanced for skewed keys too.
     """
     import torch
     import torch.distributed as dist
@@ -86,8 +119,13 @@ def distributed_sort(local_keys, backend=None, group=None, exchange_always: bool
         n = out.numel()
         return ShardResult(out, 0, torch.tensor([[n]], dtype=torch.int64))
 
-    # 1. bucket b = keys whose top msb_bits equal b, contiguous, in input order
-    parted, counts = backend.msb_partition(local_keys, msb_bits)
+    # 1. bucket b = keys of rank b, contiguous, in input order
+    if partition == "splitters" and world > 1:
+        parted, counts = backend.splitter_partition(local_keys, choose_splitters(local_keys, world, group))
+    elif partition in ("msb", "splitters"):
+        parted, counts = backend.msb_partition(local_keys, msb_bits)
+    else:
+        raise ValueError(f"partition must be 'msb' or 'splitters', got {partition!r}")
     counts = counts.to(torch.int64)
 
     # 2. everyone learns the full count matrix (world x world words)

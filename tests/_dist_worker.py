@@ -27,6 +27,15 @@ class OracleBackend:
         out, counts = self.oracle.msb_partition(keys.numpy().view(np.uint32), msb_bits)
         return torch.from_numpy(out.view(np.int32)), torch.from_numpy(counts.astype(np.int64))
 
+    def splitter_partition(self, keys, splitters):
+        import torch
+
+        k = keys.numpy().view(np.uint32)
+        bucket = np.searchsorted(np.asarray(splitters, dtype=np.uint32), k, side="right")   # splitters <= key
+        order = np.argsort(bucket, kind="stable")
+        counts = np.bincount(bucket, minlength=len(splitters) + 1).astype(np.int64)
+        return torch.from_numpy(k[order].view(np.int32)), torch.from_numpy(counts)
+
     def sort_inplace(self, keys):
         import torch
 
@@ -54,6 +63,7 @@ def shard_keys(rank, n, dist_kind):
 def main():
     rank, world, port, n, dist_kind, outdir = (int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]),
                                                sys.argv[5], sys.argv[6])
+    partition = sys.argv[7] if len(sys.argv) > 7 else "msb"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     import torch
     import torch.distributed as dist
@@ -63,7 +73,7 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n_local = n + rank * 7                                    # ragged shards
     keys = shard_keys(rank, n_local, dist_kind)
-    res = distributed_sort(torch.from_numpy(keys.view(np.int32)), backend=OracleBackend())
+    res = distributed_sort(torch.from_numpy(keys.view(np.int32)), backend=OracleBackend(), partition=partition)
     np.save(os.path.join(outdir, f"out_{rank}.npy"), res.keys.numpy().view(np.uint32))
     np.save(os.path.join(outdir, f"meta_{rank}.npy"), np.array([res.global_offset, n_local], dtype=np.int64))
     np.save(os.path.join(outdir, f"counts_{rank}.npy"), res.counts.numpy())

@@ -56,6 +56,37 @@ def test_msb_bucket_exchange(tmp_path, oracle_mod, world, kind):
         assert outs[0].size == expect.size           # fixed MSB buckets do not balance skewed input
 
 
+@pytest.mark.parametrize("world,kind", [(2, "skew"), (4, "skew"), (4, "uniform"), (2, "dup")])
+def test_sampled_splitter_exchange(tmp_path, oracle_mod, world, kind):
+    """partition="splitters" (SURVEY section 8f.2): the rank-order concatenation is still the global sort,
+    and skewed keys that fixed MSB buckets pile onto rank 0 now spread over the ranks."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _dist_worker import shard_keys
+
+    n = 20000
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(r), str(world), port,
+                               str(n), kind, str(tmp_path), "splitters"]) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=180) == 0
+    everything = np.concatenate([shard_keys(r, n + 7 * r, kind) for r in range(world)])
+    expect = oracle_mod.std_sort(everything)
+    outs = [np.load(tmp_path / f"out_{r}.npy") for r in range(world)]
+    metas = [np.load(tmp_path / f"meta_{r}.npy") for r in range(world)]
+    assert np.array_equal(np.concatenate(outs), expect), "rank-order concatenation is not the global sort"
+    offset = 0
+    for r in range(world):
+        assert int(metas[r][0]) == offset
+        offset += outs[r].size
+    counts = np.load(tmp_path / "counts_0.npy")
+    assert counts.shape == (world, world) and int(counts.sum()) == expect.size
+    for r in range(world):
+        assert int(counts[:, r].sum()) == outs[r].size
+    if kind in ("skew", "uniform"):                      # distinct-ish keys: every rank within 10 % of its share
+        share = expect.size / world
+        assert all(abs(o.size - share) < 0.10 * share for o in outs), [o.size for o in outs]
+
+
 def test_world_size_must_be_power_of_two():
     from lsdradixsort_amd.dist import _log2_exact
 

@@ -350,6 +350,27 @@ def test_rccl_exchange_path_world_of_one(gpu, oracle_mod):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("nsplit", [0, 1, 3, 7])
+def test_splitter_partition(gpu, oracle_mod, nsplit):
+    """Partition by value (multi-GPU step 1 for skewed keys): bucket = number of splitters <= key, stable,
+    against numpy's searchsorted + stable argsort; ragged sizes, keys equal to splitters, empty buckets."""
+    rng = np.random.default_rng(5 + nsplit)
+    for n, seed in ((1, 1), (4097, 2), ((1 << 20) + 7, 3), ((1 << 23) + 1001, 4)):
+        keys = oracle_mod.mt19937_keys(n, seed)
+        if seed == 3:
+            keys = (keys >> np.uint32(5)).astype(np.uint32)          # skewed: top five bits clear
+        splitters = np.sort(rng.choice(keys, size=nsplit, replace=True)) if nsplit else np.zeros(0, dtype=np.uint32)
+        if nsplit >= 3 and seed == 2:
+            splitters[1] = splitters[0]                               # an empty bucket
+        out, counts = gpu.SplitterPartition(gpu.to_device(keys), [int(x) for x in splitters])
+        bucket = np.searchsorted(splitters, keys, side="right")
+        order = np.argsort(bucket, kind="stable")
+        assert np.array_equal(counts.cpu().numpy(), np.bincount(bucket, minlength=nsplit + 1)), (nsplit, n)
+        assert np.array_equal(gpu.to_host(out), keys[order]), (nsplit, n)
+    with pytest.raises(Exception):
+        gpu.SplitterPartition(gpu.to_device(keys), [5, 4, 9])        # not ascending
+
+
 # ----------------------------------------------------------------------------- full size, by property
 def _as_u64(t):
     import torch

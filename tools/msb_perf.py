@@ -20,7 +20,10 @@ def timed(fn, reps=5):
     return float(np.median(ts))
 
 
-for method in (0, 2):
+sp = [int(x) for x in np.linspace(0, 2**32, 9)[1:-1]]
+for k in (1, 3, 7):
+    print(f"splitter partition, {k} splitters: {timed(lambda: lsd.SplitterPartition(d, sp[:k] if k < 7 else sp)):.3f} ms", flush=True)
+for method in (0,):
     lsd.set_rank_method(method)
     for bits in (1, 2, 3):
         print(f"rank_method={method} msb_bits={bits} partition {timed(lambda: lsd.MSBPartition(d, bits)):.3f} ms", flush=True)
