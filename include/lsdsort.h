@@ -98,6 +98,16 @@ LSDSORT_API int lsdsort_u32_device_ex(uint32_t* d_keys, uint32_t* d_vals, void* 
                                       size_t workspace_bytes, size_t n, int radix_bits,
                                       int algorithm, void* hip_stream);
 
+/* Keys of another 32-bit type or order (no reference counterpart: it sorts ascending uint32 only,
+ * .cu:62).  The keys are mapped to order-preserving uint32 where they are first read
+ * (upfront histogram, first pass) and mapped back where the last pass stores them: same passes, same
+ * traffic as lsdsort_u32_device.  float32 sorts in IEEE total order (-NaN < -inf < ... < -0 < +0 < ... <
+ * +inf < +NaN).  Descending = ascending on the complemented key; with payloads it is stable (equal keys
+ * keep their input order).  d_vals may be NULL.  Chained algorithm, radix_bits 4 or 8. */
+typedef enum lsdsort_key_type { LSDSORT_KEY_U32 = 0, LSDSORT_KEY_I32 = 1, LSDSORT_KEY_F32 = 2 } lsdsort_key_type;
+LSDSORT_API int lsdsort_keys_device(void* d_keys, uint32_t* d_vals, void* d_workspace, size_t workspace_bytes,
+                                    size_t n, int radix_bits, int key_type, int descending, void* hip_stream);
+
 /* After the stream has drained: LSDSORT_OK, or LSDSORT_ERR_DEVICE_FAULT if a kernel of the
  * last sort on this workspace gave up a bounded spin (never expected; the output is then
  * undefined).  Synchronises hip_stream. */

@@ -44,6 +44,7 @@ SIGNATURES = {
     "lsdsort_u32_device": (c_int, [c_u32p, ctypes.c_void_p, c_size, c_size, c_int, ctypes.c_void_p]),
     "lsdsort_pairs_u32_device": (c_int, [c_u32p, c_u32p, ctypes.c_void_p, c_size, c_size, c_int, ctypes.c_void_p]),
     "lsdsort_u32_device_ex": (c_int, [c_u32p, c_u32p, ctypes.c_void_p, c_size, c_size, c_int, c_int, ctypes.c_void_p]),
+    "lsdsort_keys_device": (c_int, [ctypes.c_void_p, c_u32p, ctypes.c_void_p, c_size, c_size, c_int, c_int, c_int, ctypes.c_void_p]),
     "lsdsort_check_device": (c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "lsdsort_u32_device_timed": (c_int, [c_u32p, c_u32p, ctypes.c_void_p, c_size, c_size, c_int, c_int,
                                          ctypes.c_void_p, ctypes.POINTER(LsdsortTiming)]),

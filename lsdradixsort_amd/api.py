@@ -19,7 +19,7 @@ from .errors import LSDSORT_ALGO_ONESWEEP, LSDSORT_ALGO_STAGED, check
 __all__ = [
     "sort", "sort_pairs", "to_device", "to_host", "workspace_bytes", "GPULSDRadixSort",
     "GPULSDRadixSortTimed", "BuildHistograms", "BuildOffsets", "RankScatter", "DigitHistograms",
-    "MSBPartition", "SplitterPartition", "tile_keys", "set_tile_config", "set_rank_method", "rank_method", "set_xcd_chunk", "LSDSORT_ALGO_ONESWEEP", "LSDSORT_ALGO_STAGED",
+    "MSBPartition", "SplitterPartition", "GPUSortTyped", "tile_keys", "set_tile_config", "set_rank_method", "rank_method", "set_xcd_chunk", "LSDSORT_ALGO_ONESWEEP", "LSDSORT_ALGO_STAGED",
 ]
 
 
@@ -141,6 +141,33 @@ def GPULSDRadixSort(d_keys, r: int = 8, d_vals=None, algorithm: int = LSDSORT_AL
     st = lib().lsdsort_u32_device_ex(d_keys.data_ptr(), d_vals.data_ptr() if pairs else None, workspace.data_ptr(),
                                      workspace.numel(), n, r, algorithm, _stream(stream))
     check(st, "lsdsort_u32_device_ex")
+    if check_fault and n:
+        check(lib().lsdsort_check_device(workspace.data_ptr(), _stream(stream)), "lsdsort_check_device")
+    return d_keys if not pairs else (d_keys, d_vals)
+
+
+_KEY_TYPES = {"uint32": 0, "int32": 1, "float32": 2}
+
+
+def GPUSortTyped(d_keys, key_type: str = "int32", descending: bool = False, d_vals=None, r: int = 8, workspace=None,
+                 stream=None, check_fault: bool = False):
+    """Device-resident sort of 32-bit keys of another type or order (``lsdsort_keys_device``): ``key_type`` in
+    "uint32" / "int32" / "float32" says how the 32 bits of each element of ``d_keys`` (an int32 or float32 CUDA
+    tensor) compare; float32 uses IEEE total order.  Stable with ``d_vals`` (int32 payloads).  In place."""
+    torch = _torch()
+    if not (d_keys.is_cuda and d_keys.is_contiguous() and d_keys.dtype in (torch.int32, torch.float32)):
+        raise TypeError("d_keys: a contiguous int32 or float32 CUDA tensor")
+    n = d_keys.numel()
+    pairs = d_vals is not None
+    if pairs:
+        _dev_i32(d_vals, "d_vals")
+        if d_vals.numel() != n:
+            raise ValueError("keys and vals differ in length")
+    if workspace is None:
+        workspace = alloc_workspace(n, r, pairs, LSDSORT_ALGO_ONESWEEP, d_keys.device)
+    check(lib().lsdsort_keys_device(d_keys.data_ptr(), d_vals.data_ptr() if pairs else None, workspace.data_ptr(),
+                                    workspace.numel(), n, r, _KEY_TYPES[key_type], int(bool(descending)), _stream(stream)),
+          "lsdsort_keys_device")
     if check_fault and n:
         check(lib().lsdsort_check_device(workspace.data_ptr(), _stream(stream)), "lsdsort_check_device")
     return d_keys if not pairs else (d_keys, d_vals)

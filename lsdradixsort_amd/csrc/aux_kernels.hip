@@ -229,7 +229,7 @@ hipError_t launch_scan_digit_counts(int radix_bits, int groups, const uint32_t* 
 template <int R, int THREADS, bool WIDE = false>
 __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                   uint32_t region0_keys, uint32_t* __restrict__ joint,
-                                                                  uint32_t vec_chunks)
+                                                                  uint32_t vec_chunks, const KeyTransform xf)
 {
     static_assert(!WIDE || R == 4, "wide fields are laid out for 4-bit digits with 4 region bits");
     constexpr int P = 32 / R;
@@ -372,6 +372,11 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
             const uint32_t cc = c + u;
             v[u] = cc < vec_chunks ? keys4[(size_t)cc * THREADS + tid] : make_uint4(0, 0, 0, 0);
         }
+        if (xf.on) {   // typed sorts count the "sortable" form of the keys (uniform branch)
+#pragma unroll
+            for (int u = 0; u < VPT; u++)
+                v[u] = make_uint4(to_sortable(v[u].x, xf), to_sortable(v[u].y, xf), to_sortable(v[u].z, xf), to_sortable(v[u].w, xf));
+        }
     };
     const uint32_t stride = gridDim.x * VPT;
     uint32_t c = blockIdx.x * VPT;
@@ -402,7 +407,8 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
     }
     if (blockIdx.x == 0) {
         const uint32_t tail_begin = vec_chunks * (THREADS * 4);
-        for (uint32_t i = tail_begin + tid; i < n; i += THREADS) count_key_checked(keys[i], i / region0_keys);
+        for (uint32_t i = tail_begin + tid; i < n; i += THREADS)
+            count_key_checked(xf.on ? to_sortable(keys[i], xf) : keys[i], i / region0_keys);
     }
     __syncthreads();
     // Flush.  Pass 0's fields sit region-major in LDS: all 64 lanes of a wave share their position
@@ -441,7 +447,7 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
 
 template <int R, int THREADS, bool WIDE = false>
 static hipError_t launch_joint_inst(const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* joint,
-                                    hipStream_t stream)
+                                    hipStream_t stream, const KeyTransform& xf)
 {
     constexpr int P = 32 / R;
     constexpr int F = (1 << R) << region_bits_for_radix(R);
@@ -462,20 +468,20 @@ static hipError_t launch_joint_inst(const uint32_t* keys, uint32_t n, uint32_t r
     const uint32_t cap = (uint32_t)(2048 * 256 / THREADS);   // enough waves to cover HBM latency
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds_bytes, stream, keys, n, region0_keys, joint, vec_chunks);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds_bytes, stream, keys, n, region0_keys, joint, vec_chunks, xf);
     return hipGetLastError();
 }
 
 hipError_t launch_joint_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys,
-                                   uint32_t* joint, hipStream_t stream)
+                                   uint32_t* joint, hipStream_t stream, const KeyTransform& xf)
 {
     switch (radix_bits) {
 #ifdef LSD_R4_NARROW_HIST
-        case 4: return launch_joint_inst<4, 256>(keys, n, region0_keys, joint, stream);
+        case 4: return launch_joint_inst<4, 256>(keys, n, region0_keys, joint, stream, xf);
 #else
-        case 4: return launch_joint_inst<4, LSD_R4_HIST_THREADS, true>(keys, n, region0_keys, joint, stream);   // 64 KiB of counters per workgroup
+        case 4: return launch_joint_inst<4, LSD_R4_HIST_THREADS, true>(keys, n, region0_keys, joint, stream, xf);   // 64 KiB of counters per workgroup
 #endif
-        case 8: return launch_joint_inst<8, (LSD_R8_REGION_BITS == 3 ? 256 : LSD_R8_HIST_THREADS)>(keys, n, region0_keys, joint, stream);   // 32 / 64 / 128 KiB of counters per workgroup at 3 / 4 / 5 bits
+        case 8: return launch_joint_inst<8, (LSD_R8_REGION_BITS == 3 ? 256 : LSD_R8_HIST_THREADS)>(keys, n, region0_keys, joint, stream, xf);   // 32 / 64 / 128 KiB of counters per workgroup at 3 / 4 / 5 bits
         default: return hipErrorInvalidValue;
     }
 }

@@ -50,6 +50,26 @@ inline constexpr int regions_for_radix(int radix_bits) { return 1 << region_bits
 constexpr int kRegionHeaderWords = 4 * kMaxRegions;
 inline constexpr size_t region_table_words(int radix_bits) { return kRegionHeaderWords + (size_t)kMaxRegions * ((size_t)1 << radix_bits); }
 
+// Key order other than ascending uint32: a bijection to "sortable" uint32 is applied
+// where the keys enter (upfront histogram, first pass's load) and undone where they leave (last pass's
+// store); every pass in between sees plain uint32.
+//   to sortable : t = k ^ (sext(k & a) | b) ^ c          from sortable : k = u ^ (sext(~u & a) | b),  u = t ^ c
+//   uint32: a = b = 0     int32: a = 0, b = 0x80000000     float32 (IEEE bit order): a = b = 0x80000000
+//   descending: c = 0xFFFFFFFF (ascending on the complement; stable, ties keep their input order)
+struct KeyTransform {
+    uint32_t on;   // 0: identity (a, b, c ignored)
+    uint32_t a, b, c;
+};
+__host__ __device__ inline uint32_t to_sortable(uint32_t k, const KeyTransform& x)
+{
+    return k ^ ((uint32_t)((int32_t)(k & x.a) >> 31) | x.b) ^ x.c;
+}
+__host__ __device__ inline uint32_t from_sortable(uint32_t t, const KeyTransform& x)
+{
+    const uint32_t u = t ^ x.c;
+    return u ^ ((uint32_t)((int32_t)(~u & x.a) >> 31) | x.b);
+}
+
 // Set (per host thread) around a rank-and-scatter launch by lsdsort_u32_device_timed: events that
 // receive the kernel's own begin and end timestamps (hipExtLaunchKernelGGL).
 inline thread_local hipEvent_t t_launch_start = nullptr;
@@ -80,6 +100,8 @@ struct PassParams {
     // splitters <= key (ascending splitters); shift is ignored.
     uint32_t num_splitters;
     uint32_t splitters[7];
+    KeyTransform xin;    // first pass: applied to every key as it is loaded
+    KeyTransform xout;   // last pass: undone on every key as it is stored
 };
 
 // How stage 3 ranks a key among the same-digit keys of its wave (rank_scatter.hpp).
@@ -113,7 +135,7 @@ hipError_t launch_scan_digit_counts(int radix_bits, int groups, const uint32_t* 
 // region_bits_for_radix, for every pass in one read; `region0_keys` is R0 (pass-0 regions are by
 // position).  joint must be zero on entry.
 hipError_t launch_joint_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys,
-                                   uint32_t* joint, hipStream_t stream);
+                                   uint32_t* joint, hipStream_t stream, const KeyTransform& xform = KeyTransform{});
 
 // Stage 2, onesweep: region tables of every pass from the joint counts (`regions` = 16 or 32) or
 // from plain digit histograms (`regions` = 1; passes may then be 1 for the multi-GPU partition).

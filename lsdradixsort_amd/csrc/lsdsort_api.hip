@@ -277,8 +277,10 @@ struct StageEvents {
 // 3 after stage 2 | 4 after the last pass.  Staged: 0 start | 1 after clear | 2, 3 (empty) | then per
 // pass three marks: after its histogram, after its offset scan, after its scatter.
 int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, size_t n, int radix_bits,
-             int algorithm, hipStream_t stream, StageEvents* ev, lsdsort_timing* timing)
+             int algorithm, hipStream_t stream, StageEvents* ev, lsdsort_timing* timing,
+             const lsd::KeyTransform& xf = lsd::KeyTransform{})
 {
+    if (xf.on && (algorithm != LSDSORT_ALGO_ONESWEEP || radix_bits < 4)) return LSDSORT_ERR_UNSUPPORTED;
     if (!valid_radix(radix_bits)) return LSDSORT_ERR_INVALID_ARG;
     if (algorithm != LSDSORT_ALGO_ONESWEEP && algorithm != LSDSORT_ALGO_STAGED) return LSDSORT_ERR_INVALID_ARG;
     if (n > LSDSORT_MAX_KEYS) return LSDSORT_ERR_TOO_LARGE;
@@ -314,7 +316,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
         uint32_t* counts = reinterpret_cast<uint32_t*>(ws + L.counts);
         tables = reinterpret_cast<uint32_t*>(ws + L.tables);
         if (L.regions > 1)
-            LSD_HIP(lsd::launch_joint_histograms(radix_bits, d_keys, (uint32_t)n, L.region0, counts, stream));
+            LSD_HIP(lsd::launch_joint_histograms(radix_bits, d_keys, (uint32_t)n, L.region0, counts, stream, xf));
         else
             LSD_HIP(lsd::launch_digit_histograms(radix_bits, passes, 0, d_keys, (uint32_t)n, counts, stream));
         if (ev) LSD_TRY(ev->mark());
@@ -355,6 +357,8 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             p.status_clear = pass + 1 < passes ? reinterpret_cast<uint32_t*>(ws + ((pass & 1) ? L.status : L.status_odd)) : nullptr;
             p.tickets = reinterpret_cast<uint32_t*>(ws + L.tickets) + (size_t)pass * lsd::kMaxRegions;
             p.parity = 0;
+            if (xf.on && pass == 0) p.xin = xf;
+            if (xf.on && pass + 1 == passes) p.xout = xf;
             if (ev) LSD_TRY(ev->arm_kernel_events());
             const hipError_t launched = lsd::launch_rank_scatter(radix_bits, *shape, rank_method, true, p, stream);
             StageEvents::disarm_kernel_events();
@@ -593,6 +597,22 @@ int lsdsort_pairs_u32_device(uint32_t* d_keys, uint32_t* d_vals, void* d_workspa
     if (n > 0 && !d_vals) return LSDSORT_ERR_INVALID_ARG;
     return lsdsort_u32_device_ex(d_keys, d_vals, d_workspace, workspace_bytes, n, radix_bits, LSDSORT_ALGO_ONESWEEP,
                                  hip_stream);
+}
+
+int lsdsort_keys_device(void* d_keys, uint32_t* d_vals, void* d_workspace, size_t workspace_bytes, size_t n,
+                        int radix_bits, int key_type, int descending, void* hip_stream)
+{
+    lsd::KeyTransform xf{};
+    switch (key_type) {
+        case LSDSORT_KEY_U32: break;
+        case LSDSORT_KEY_I32: xf.b = 0x80000000u; break;
+        case LSDSORT_KEY_F32: xf.a = 0x80000000u; xf.b = 0x80000000u; break;
+        default: return LSDSORT_ERR_INVALID_ARG;
+    }
+    if (descending) xf.c = 0xFFFFFFFFu;
+    xf.on = (xf.a | xf.b | xf.c) != 0u;
+    return run_sort(static_cast<uint32_t*>(d_keys), d_vals, d_workspace, workspace_bytes, n, radix_bits, LSDSORT_ALGO_ONESWEEP,
+                    static_cast<hipStream_t>(hip_stream), nullptr, nullptr, xf);
 }
 
 int lsdsort_check_device(void* d_workspace, void* hip_stream)

@@ -117,7 +117,9 @@ constexpr int rank_scatter_lds_words()
     return buf + W * H + H + 32 + Lookback<R, T>::LDS_WORDS;
 }
 
-template <int R, int T, int K, int CAP, int RANK, bool PAIRS, bool CHAINED>
+// XF: this launch may carry a key transform (PassParams::xin on a sort's first pass, ::xout on its last);
+// plain uint32 sorts use the XF = false instantiations, which contain none of it.
+template <int R, int T, int K, int CAP, int RANK, bool PAIRS, bool CHAINED, bool XF = false>
 __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_kernel(const PassParams p)
 {
 #ifdef LSD_PHASE_STATS
@@ -164,6 +166,12 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             }
         }
         return digit_at<R>(k, shift);
+    };
+    // A key on its way out: the last pass of a typed sort undoes the transform (XF launches only).
+    const bool undo = XF && p.xout.on;
+    auto leaving = [&](uint32_t k) -> uint32_t {
+        if constexpr (XF) return undo ? from_sortable(k, p.xout) : k;
+        return k;
     };
 
     if (CHAINED && p.status_clear) {
@@ -285,6 +293,14 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         for (int i = 0; i < K; i++) {
             const uint32_t idx = first + i * kWave;
             key[i] = idx < range_end ? keys_in[i * kWave] : 0xFFFFFFFFu;
+        }
+    }
+
+    if constexpr (XF) {
+        if (p.xin.on) {   // first pass of a typed sort: keys become "sortable" uint32 (padding stays the maximum)
+#pragma unroll
+            for (int i = 0; i < K; i++)
+                if (full || first + i * kWave < range_end) key[i] = to_sortable(key[i], p.xin);
         }
     }
 
@@ -576,7 +592,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                 const uint32_t d = digit_of(k);
                 if ((s2 & 3) == 0) dbytes[s2 / 4] = d;
                 else dbytes[s2 / 4] |= d << (8 * (s2 & 3));
-                if (full || q < valid) p.out[s_gdelta[d] + q] = k;
+                if (full || q < valid) p.out[s_gdelta[d] + q] = leaving(k);
                 if ((s2 & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep at most eight slots in flight
             }
         } else if (PREREAD) {
@@ -585,7 +601,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                 const uint32_t q = s2 * T + tid;
                 const uint32_t k = back[PREREAD ? s2 : 0];
                 const uint32_t d = digit_of(k);
-                if (full || q < valid) p.out[s_gdelta[d] + q] = k;
+                if (full || q < valid) p.out[s_gdelta[d] + q] = leaving(k);
             }
         } else {
             // keys only: sixteen slots at a time, which bounds the registers of the read-back
@@ -598,7 +614,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                     const uint32_t q = round * CAP + slot;
                     const uint32_t k = s_keys[slot];
                     const uint32_t d = digit_of(k);
-                    if (full || q < valid) p.out[s_gdelta[d] + q] = k;
+                    if (full || q < valid) p.out[s_gdelta[d] + q] = leaving(k);
                 }
             }
         }
@@ -628,11 +644,11 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
 }
 
 // Launch one instantiation.  LDS above 64 KiB needs the attribute raised once per function.
-template <int R, int T, int K, int CAP, int RANK, bool PAIRS, bool CHAINED>
+template <int R, int T, int K, int CAP, int RANK, bool PAIRS, bool CHAINED, bool XF = false>
 hipError_t launch_rank_scatter_inst(const PassParams& p, hipStream_t stream)
 {
     constexpr size_t lds_bytes = (size_t)rank_scatter_lds_words<R, T, K, CAP, RANK>() * sizeof(uint32_t);
-    auto kernel = rank_scatter_kernel<R, T, K, CAP, RANK, PAIRS, CHAINED>;
+    auto kernel = rank_scatter_kernel<R, T, K, CAP, RANK, PAIRS, CHAINED, XF>;
     if (lds_bytes > 64 * 1024) {
         static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -665,6 +681,15 @@ template <int R, int T, int K, int CAP, int RANK>
 hipError_t launch_rank_scatter_rank(bool chained, const PassParams& p, hipStream_t stream)
 {
     const bool pairs = p.vals_in != nullptr;
+    if (p.xin.on || p.xout.on) {
+        // typed sorts (int32 / float32 / descending): chained form, 4- and 8-bit digits
+        if constexpr (R >= 4) {
+            if (chained)
+                return pairs ? launch_rank_scatter_inst<R, T, K, CAP, RANK, true, true, true>(p, stream)
+                             : launch_rank_scatter_inst<R, T, K, CAP, RANK, false, true, true>(p, stream);
+        }
+        return hipErrorInvalidValue;
+    }
     if (chained)
         return pairs ? launch_rank_scatter_inst<R, T, K, CAP, RANK, true, true>(p, stream)
                      : launch_rank_scatter_inst<R, T, K, CAP, RANK, false, true>(p, stream);

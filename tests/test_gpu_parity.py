@@ -371,6 +371,84 @@ def test_splitter_partition(gpu, oracle_mod, nsplit):
         gpu.SplitterPartition(gpu.to_device(keys), [5, 4, 9])        # not ascending
 
 
+# ----------------------------------------------------------------------------- other key types and orders
+@pytest.mark.parametrize("r", [8, 4])
+@pytest.mark.parametrize("descending", [False, True])
+@pytest.mark.parametrize("key_type", ["uint32", "int32", "float32"])
+def test_typed_keys(gpu, oracle_mod, key_type, descending, r):
+    """int32 / float32 / descending orders, fused into the first pass's load and the last pass's store:
+    against numpy's sort of the typed view; float32 includes +-0, +-inf, denormals (no NaN: numpy and IEEE
+    total order place them differently)."""
+    import torch
+
+    for n, seed in ((0, 1), (1, 1), (4097, 2), ((1 << 20) + 13, 3), ((1 << 23) + 5, 4)):
+        raw = oracle_mod.mt19937_keys(n, seed)
+        if key_type == "float32":
+            f = raw.view(np.float32).copy()
+            f[np.isnan(f)] = np.float32(1.5)
+            if n > 16:
+                f[:8] = np.array([0.0, -0.0, np.inf, -np.inf, 1e-45, -1e-45, 3.4e38, -3.4e38], dtype=np.float32)
+            host = f
+            t = torch.from_numpy(host.copy()).cuda()
+        elif key_type == "int32":
+            host = raw.view(np.int32)
+            t = torch.from_numpy(host.copy()).cuda()
+        else:
+            host = raw
+            t = gpu.to_device(raw)
+        gpu.GPUSortTyped(t, key_type, descending, r=r, check_fault=True)
+        got = t.cpu().numpy() if key_type != "uint32" else gpu.to_host(t)
+        expect = np.sort(host)
+        if descending:
+            expect = expect[::-1]
+        if key_type == "float32":       # bit-exact, not just ==: -0 must come before +0 ascending
+            expect_bits = np.sort(oracle_float_key(host))
+            if descending:
+                expect_bits = expect_bits[::-1]
+            assert np.array_equal(oracle_float_key(got), expect_bits), (key_type, descending, n)
+        assert np.array_equal(got, expect), (key_type, descending, n)
+
+
+def oracle_float_key(f):
+    """IEEE total-order key of float32 values as uint32 (numpy restatement of the transform under test)."""
+    u = np.asarray(f, dtype=np.float32).view(np.uint32)
+    neg = (u >> np.uint32(31)).astype(bool)
+    return np.where(neg, ~u, u | np.uint32(0x80000000)).astype(np.uint32)
+
+
+@pytest.mark.parametrize("key_type,descending", [("int32", True), ("float32", False), ("uint32", True)])
+def test_typed_pairs_are_stable(gpu, oracle_mod, key_type, descending):
+    import torch
+
+    n = (1 << 20) + 3
+    raw = (oracle_mod.mt19937_keys(n, 9) >> np.uint32(22)).astype(np.uint32)     # 1024 distinct values: many ties
+    if key_type == "float32":
+        host = (raw.astype(np.float32) - np.float32(500.0))
+        t = torch.from_numpy(host.copy()).cuda()
+    elif key_type == "int32":
+        host = raw.astype(np.int32) - np.int32(500)
+        t = torch.from_numpy(host.copy()).cuda()
+    else:
+        host = raw
+        t = gpu.to_device(raw)
+    vals = torch.arange(n, dtype=torch.int32, device="cuda")
+    gpu.GPUSortTyped(t, key_type, descending, d_vals=vals, check_fault=True)
+    order = np.argsort(-host.astype(np.float64) if descending else host, kind="stable")
+    assert np.array_equal(vals.cpu().numpy(), order.astype(np.int32))
+    got = t.cpu().numpy() if key_type != "uint32" else gpu.to_host(t)
+    assert np.array_equal(got, host[order])
+
+
+def test_typed_sort_limits(gpu):
+    import torch
+    from lsdradixsort_amd import errors
+
+    t = torch.zeros(100, dtype=torch.int32, device="cuda")
+    ws = gpu.alloc_workspace(100, 8)
+    assert gpu.lib().lsdsort_keys_device(t.data_ptr(), None, ws.data_ptr(), ws.numel(), 100, 8, 7, 0, None) == errors.LSDSORT_ERR_INVALID_ARG
+    assert gpu.lib().lsdsort_keys_device(t.data_ptr(), None, ws.data_ptr(), ws.numel(), 100, 2, 1, 0, None) == errors.LSDSORT_ERR_UNSUPPORTED
+
+
 # ----------------------------------------------------------------------------- full size, by property
 def _as_u64(t):
     import torch
