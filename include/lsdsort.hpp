@@ -51,4 +51,24 @@ inline void sort_pairs_device(uint32_t* d_keys, uint32_t* d_vals, void* d_worksp
           "lsdsort_pairs_u32_device");
 }
 
+// Other 32-bit key types and orders (no reference counterpart): the overload picks the key type.
+inline void sort_device(int32_t* d_keys, void* d_workspace, size_t workspace_bytes_, size_t n, bool descending = false,
+                        uint32_t* d_vals = nullptr, int radix_bits = 8, void* hip_stream = nullptr)
+{
+    check(lsdsort_keys_device(d_keys, d_vals, d_workspace, workspace_bytes_, n, radix_bits, LSDSORT_KEY_I32, descending ? 1 : 0,
+                              hip_stream), "lsdsort_keys_device");
+}
+inline void sort_device(float* d_keys, void* d_workspace, size_t workspace_bytes_, size_t n, bool descending = false,
+                        uint32_t* d_vals = nullptr, int radix_bits = 8, void* hip_stream = nullptr)
+{
+    check(lsdsort_keys_device(d_keys, d_vals, d_workspace, workspace_bytes_, n, radix_bits, LSDSORT_KEY_F32, descending ? 1 : 0,
+                              hip_stream), "lsdsort_keys_device");
+}
+inline void sort_device_descending(uint32_t* d_keys, void* d_workspace, size_t workspace_bytes_, size_t n,
+                                   uint32_t* d_vals = nullptr, int radix_bits = 8, void* hip_stream = nullptr)
+{
+    check(lsdsort_keys_device(d_keys, d_vals, d_workspace, workspace_bytes_, n, radix_bits, LSDSORT_KEY_U32, 1, hip_stream),
+          "lsdsort_keys_device");
+}
+
 }  // namespace lsd
