@@ -91,6 +91,9 @@ def test_narrow_radix_vs_oracle(gpu, oracle_mod, r):
     keys = oracle_mod.mt19937_keys((1 << 18) + 77, 12)
     for algo in ALGOS.values():
         assert np.array_equal(_sort_dev(gpu, keys, r, algo), oracle_mod.std_sort(keys))
+    for n in ((1 << 21) + 5, (1 << 23) + 9):               # the larger tiles narrow digits use from 2^21 / 2^23 keys
+        keys = oracle_mod.mt19937_keys(n, 13)
+        assert np.array_equal(_sort_dev(gpu, keys, r), np.sort(keys)), (r, n)
 
 
 @pytest.mark.parametrize("r", [4, 8])
