@@ -117,6 +117,38 @@ def test_distributions(gpu, oracle_mod, r):
         assert np.array_equal(got, np.sort(keys)), (name, r)
 
 
+def test_randomised_shapes_of_input(gpu, oracle_mod):
+    """Seeded sweep over sizes, radix widths and key shapes that steer the low-entropy paths of stage 1
+    (wave-uniform fields, edge groups, few-valued digits) and of the rank phase: random bit masks, sorted /
+    nearly sorted / run-structured keys, ragged sizes around tile and chunk boundaries.  Against numpy."""
+    rng = np.random.default_rng(20260)
+    sizes = [1, 2, 63, 64, 65, 255, 1023, 1025, 2047, 2049, 4095, 4097, 8191, 16385, 32769, 65537, (1 << 19) - 3, (1 << 19) + 3,
+             (1 << 21) + 11, (1 << 22) - 1]
+    for case in range(64):
+        n = int(sizes[case % len(sizes)] if case < 40 else rng.integers(1, 1 << 21))
+        r = (8, 4, 8, 2, 8, 4, 8, 1)[case % 8]
+        if r <= 2 and n > (1 << 18):
+            r = 4
+        base = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+        kind = case % 7
+        if kind == 1:
+            base = np.sort(base)
+        elif kind == 2:
+            base &= np.uint32(rng.integers(0, 1 << 32))                       # random dead bits
+        elif kind == 3:
+            base = np.sort(base)
+            swap = rng.integers(0, n, size=max(1, n // 100))
+            base[swap] = rng.integers(0, 1 << 32, size=swap.size, dtype=np.uint64).astype(np.uint32)   # nearly sorted
+        elif kind == 4:
+            base = np.repeat(base[: max(1, n // 300)], 300)[:n] if n >= 300 else base                 # runs of equal keys
+        elif kind == 5:
+            base = (base % np.uint32(rng.integers(1, 40))) * np.uint32(0x01010101)                    # few values per byte
+        elif kind == 6:
+            base = np.sort(base)[::-1].copy()
+        got = _sort_dev(gpu, base, r)
+        assert np.array_equal(got, np.sort(base)), (case, n, r, kind)
+
+
 @pytest.mark.parametrize("r", [4, 8])
 def test_pairs_vs_stable_sort(gpu, oracle_mod, r):
     n = (1 << 20) + 9
