@@ -174,13 +174,16 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         return k;
     };
 
-    if (CHAINED && p.status_clear) {
-        // housekeeping for the NEXT pass (it runs in the other status array): the grid's workgroups
-        // share the rows out (one each when the grid is the row count)
-        for (uint32_t row = blockIdx.x; row < p.num_tiles; row += gridDim.x)
-            for (uint32_t i = tid; i < (uint32_t)H; i += (uint32_t)T) p.status_clear[(size_t)row * H + i] = 0;
-    }
-
+    // Housekeeping for the NEXT pass (it runs in the other status array): the grid's workgroups share the
+    // rows out (one each when the grid is the row count).  Called behind the key loads in issue order:
+    // memory operations of a wave retire in order, and in front of the ticket or the loads these
+    // stores' acknowledgements would be waited for with them.
+    auto clear_next = [&]() {
+        if (CHAINED && p.status_clear) {
+            for (uint32_t row = blockIdx.x; row < p.num_tiles; row += gridDim.x)
+                for (uint32_t i = tid; i < (uint32_t)H; i += (uint32_t)T) p.status_clear[(size_t)row * H + i] = 0;
+        }
+    };
 
     // wave-private tables start at zero
 #pragma unroll
@@ -239,7 +242,10 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         }
         __syncthreads();
         region = __builtin_amdgcn_readfirstlane(s_misc[28]);
-        if (region == 0xFFFFFFFFu) return;   // uniform: the grid is an upper bound on the tile count
+        if (region == 0xFFFFFFFFu) {         // uniform: the grid is an upper bound on the tile count
+            clear_next();
+            return;
+        }
         chain_pos = __builtin_amdgcn_readfirstlane(s_misc[29]);
         const uint32_t r_start = __builtin_amdgcn_readfirstlane(s_misc[24]);
         const uint32_t r_len = __builtin_amdgcn_readfirstlane(s_misc[25]);
@@ -295,6 +301,8 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             key[i] = idx < range_end ? keys_in[i * kWave] : 0xFFFFFFFFu;
         }
     }
+
+    clear_next();
 
     if constexpr (XF) {
         if (p.xin.on) {   // first pass of a typed sort: keys become "sortable" uint32 (padding stays the maximum)
