@@ -592,6 +592,11 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         // destination can be rebuilt without keeping SLOTS addresses alive
         uint32_t dbytes[PAIRS ? (SLOTS + 3) / 4 : 1];
         if (PAIRS) {
+            // The payload loads have had the whole look-back to arrive: take them NOW, before the key stores
+            // are issued.  A wave's memory operations retire in issue order, so a wait for the payloads placed
+            // behind those stores (where the payloads are used) would also wait for every store's acknowledgement.
+#pragma unroll
+            for (int i = 0; i < K; i++) asm volatile("" : "+v"(val[i]));
 #pragma unroll
             for (int s2 = 0; s2 < SLOTS; s2++) {
                 const uint32_t slot = s2 * T + tid;
