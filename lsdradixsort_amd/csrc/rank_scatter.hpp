@@ -175,9 +175,9 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     };
 
     // Housekeeping for the NEXT pass (it runs in the other status array): the grid's workgroups share the
-    // rows out (one each when the grid is the row count).  Called behind the key loads in issue order:
-    // memory operations of a wave retire in order, and in front of the ticket or the loads these
-    // stores' acknowledgements would be waited for with them.
+    // rows out (one each when the grid is the row count).  Called after the look-back, where no load of the
+    // wave is waited for any more: memory operations of a wave retire in issue order, so in front of the
+    // ticket, the key loads or the status loads these stores' acknowledgements would be waited for as well.
     auto clear_next = [&]() {
         if (CHAINED && p.status_clear) {
             for (uint32_t row = blockIdx.x; row < p.num_tiles; row += gridDim.x)
@@ -301,8 +301,6 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             key[i] = idx < range_end ? keys_in[i * kWave] : 0xFFFFFFFFu;
         }
     }
-
-    clear_next();
 
     if constexpr (XF) {
         if (p.xin.on) {   // first pass of a typed sort: keys become "sortable" uint32 (padding stays the maximum)
@@ -585,6 +583,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         }
         lds_barrier();
         if (round == 0) LSD_STAMP(5);   // look-back (wave 0's digits) + barrier
+        if (round == 0) clear_next();   // no load of this wave is waited for from here on
 
         // linear read-back: consecutive threads hold consecutive tile positions, so each digit's
         // keys leave as one contiguous run
