@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Bounded soak (GPU box): a few hundred sorts of random size / radix / kind back to back on two streams, each
+checked against torch.sort.  Looks for rare protocol problems (chain spins, fault word), not for speed."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import lsdradixsort_amd as lsd
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
+budget_s = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+lo_lg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+hi_lg = int(sys.argv[4]) if len(sys.argv) > 4 else 24
+streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+gen = torch.Generator(device="cuda"); gen.manual_seed(99)
+t0 = time.time(); done = 0
+while time.time() - t0 < budget_s and done < 20000:
+    lg = rng.integers(lo_lg, hi_lg + 1)
+    n = int(rng.integers(1 << max(lg - 1, 0), (1 << lg) + 1))
+    r = int(rng.choice([8, 8, 8, 4, 4, 2, 1])) if n <= (1 << 20) else int(rng.choice([8, 8, 4]))
+    kind = int(rng.integers(0, 5))
+    s = streams[done % 2]
+    with torch.cuda.stream(s):
+        k = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda", generator=gen)
+        if kind == 1:
+            k &= int(rng.integers(0, 1 << 31))
+        if kind == 2:
+            k = torch.sort(k).values
+        ws = lsd.alloc_workspace(n, r, kind == 3)
+        if kind == 3 and r >= 4:
+            v = torch.arange(n, dtype=torch.int32, device="cuda")
+            ref = torch.sort((k.to(torch.int64) & 0xFFFFFFFF), stable=True)
+            lsd.GPULSDRadixSort(k, r, d_vals=v, workspace=ws, stream=s)
+            assert torch.equal(v.to(torch.int64), ref.indices), (done, n, r, "pairs")
+            assert torch.equal(k.to(torch.int64) & 0xFFFFFFFF, ref.values), (done, n, r, "pairs keys")
+        elif kind == 4 and r >= 4:
+            ref = torch.sort(k, descending=bool(done & 1)).values
+            lsd.GPUSortTyped(k, "int32", bool(done & 1), r=r, workspace=ws, stream=s)
+            assert torch.equal(k, ref), (done, n, r, "int32")
+        else:
+            ref = torch.sort(k.to(torch.int64) & 0xFFFFFFFF).values
+            lsd.GPULSDRadixSort(k, r, workspace=ws, stream=s)
+            assert torch.equal(k.to(torch.int64) & 0xFFFFFFFF, ref), (done, n, r, kind)
+        assert lsd.lib().lsdsort_check_device(ws.data_ptr(), s.cuda_stream) == 0, (done, "fault word")
+    done += 1
+torch.cuda.synchronize()
+print(f"soak ok: {done} sorts in {time.time() - t0:.1f} s")
