@@ -116,6 +116,8 @@ class InputPool:
 
 def main():
     args = parse_args()
+    # multi-process GPU work on this image needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
 
