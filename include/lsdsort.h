@@ -74,6 +74,9 @@ LSDSORT_API int lsdsort_u32_ex(uint32_t* keys, size_t n, int radix_bits, int num
 LSDSORT_API int lsdsort_pairs_u32(uint32_t* keys, uint32_t* vals, size_t n);
 
 /* ---- device-resident entries (the timed path) ---------------------------------------- */
+/* Threads: every call keeps its state in the workspace it is given, so calls with different workspaces may run
+ * concurrently from different host threads and on different streams; two calls sharing a workspace must be
+ * ordered by the caller (same stream, or an event).  The tuning setters (lsdsort_set_*) are process-wide. */
 
 /* Bytes of device workspace the device entries need for (n, radix_bits, pairs?, algorithm).
  * Replaces the reference's d_b + d_h + d_block_sums sizing, .cu:919-930 and

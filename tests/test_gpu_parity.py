@@ -261,6 +261,40 @@ def test_hip_graph_capture_and_replay(gpu, oracle_mod, r, pairs):
     assert gpu.lib().lsdsort_check_device(ws.data_ptr(), None) == 0
 
 
+def test_two_host_threads_two_streams(gpu, oracle_mod):
+    """Two host threads sorting at once, each on its own stream with its own workspace (ctypes drops the
+    GIL inside the library): the library keeps no per-call state outside the workspace."""
+    import threading
+    import torch
+
+    failures = []
+
+    def worker(seed):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for i in range(12):
+                    n = (1 << 16) * (1 + (seed + i) % 5) + 13 * i
+                    keys = oracle_mod.mt19937_keys(n, 100 * seed + i)
+                    r = 8 if i % 3 else 4
+                    d = gpu.to_device(keys)
+                    ws = gpu.alloc_workspace(n, r)
+                    gpu.GPULSDRadixSort(d, r, workspace=ws, stream=stream, check_fault=True)
+                    stream.synchronize()
+                    if not np.array_equal(gpu.to_host(d), np.sort(keys)):
+                        failures.append((seed, i, n, r))
+        except Exception as exc:       # noqa: BLE001 - reported below
+            failures.append((seed, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in (1, 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not failures, failures
+
+
 def test_device_entry_errors(gpu):
     import torch
 
