@@ -9,8 +9,12 @@ Contract (one JSON line on rank 0):  python bench.py --gpus N --steps K --warmup
   * input: raw std::mt19937(seed=rank) outputs (BASELINE.md section 3), resident in HBM before
     the timed region; every step sorts its own fresh copy, so no restore copy is timed.
   * timed region: barrier + torch.cuda.synchronize() on both sides of exactly K steps, MAX over
-    ranks.  N > 1 (launched by torch.distributed.run): weak scaling, MSB-bucket partition +
-    RCCL all-to-all + local sort per step (lsdradixsort_amd/dist.py); value = N * keys / time.
+    ranks.  N > 1: one rank per GPU -- either launched by torch.distributed.run (RANK/WORLD_SIZE in
+    the environment) or, when started plainly as `python bench.py --gpus N`, by this script itself: a
+    parent that never touches a GPU spawns N fresh children and relays rank 0's JSON line.  Workload
+    for N > 1 = BASELINE.json configs[3]: 2^30 keys in total (2^(30 - log2 N) per GPU, "strong"
+    scaling), MSB-bucket partition + RCCL all-to-all + local sort per step (lsdradixsort_amd/dist.py);
+    --total-log2-keys 28 gives the metric's "1 GiB at 1/2/4/8"; value = total keys / time.
   * roofline: the rank-and-scatter kernel, algorithmic bytes per launch (8 B/key: one read, one
     write) / its mean launch duration measured with hipEvents inside the library
     (lsdsort_u32_device_timed, same stream), against 8 TB/s HBM peak.
@@ -48,13 +52,17 @@ def mt19937_keys(n: int, seed: int):
     return out
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--radix-bits", type=int, default=8, choices=[1, 2, 4, 8])
-    ap.add_argument("--log2-keys", type=int, default=28, help="keys per GPU = 2^this (default 2^28 = 1 GiB)")
+    ap.add_argument("--log2-keys", type=int, default=None,
+                    help="keys per GPU = 2^this (weak scaling when given with N > 1); default: 28 at N = 1, "
+                         "--total-log2-keys minus log2 N otherwise")
+    ap.add_argument("--total-log2-keys", type=int, default=None,
+                    help="N > 1: keys over all GPUs = 2^this (default 30 = BASELINE configs[3], 4 GiB; 28 = the metric's 1 GiB)")
     ap.add_argument("--algorithm", choices=["onesweep", "staged"], default="onesweep")
     ap.add_argument("--pairs", action="store_true", help="key + uint32 payload (BASELINE configs[4])")
     ap.add_argument("--tile-config", type=int, default=-1)
@@ -67,7 +75,82 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=26)
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configs reported under 'extra'")
-    return ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.gpus not in (1, 2, 4, 8):
+        ap.error("--gpus must be 1, 2, 4 or 8 (MSB buckets: one rank per power-of-two share of the key space)")
+    return args
+
+
+def keys_per_gpu_log2(args, world):
+    """(log2 keys per GPU, scaling label).  N = 1: 2^28 (configs[2]).  N > 1: 2^30 in total unless told otherwise."""
+    if args.log2_keys is not None:
+        return args.log2_keys, "weak"
+    if world == 1:
+        return (args.total_log2_keys if args.total_log2_keys is not None else 28), "weak"
+    total = args.total_log2_keys if args.total_log2_keys is not None else 30
+    return total - (world.bit_length() - 1), "strong"
+
+
+def visible_gpus():
+    """GPUs this process could use, without initialising any (torch.cuda.device_count() does not, on this image)."""
+    import torch
+
+    return int(torch.cuda.device_count())
+
+
+def spawn_ranks(n_ranks, argv, device_count=None, child_cmd=None, timeout=None, out=sys.stdout):
+    """`python bench.py --gpus N` started plainly: be the launcher.  This parent process never touches a GPU; it
+    starts N fresh children (never an exec of a process that has initialised one) with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relays rank 0's stdout (the JSON line), and returns non-zero
+    as soon as any rank fails, stopping the others by PID."""
+    import socket
+    import subprocess
+
+    have = visible_gpus() if device_count is None else device_count
+    if have < n_ranks:
+        print(f"bench.py: --gpus {n_ranks} needs {n_ranks} visible GPUs, this machine shows {have}", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = list(child_cmd) if child_cmd is not None else [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = None if timeout is None else time.time() + timeout
+    rc = 0
+    pending = set(range(n_ranks))
+    while pending and rc == 0:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0:
+                    print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+                    rc = code if code > 0 else 1
+        if deadline is not None and time.time() > deadline:
+            print("bench.py: ranks timed out", file=sys.stderr)
+            rc = 124
+        if pending and rc == 0:
+            time.sleep(0.05)
+    for r in pending:                      # a rank failed or timed out: stop the others (our own children, by PID)
+        procs[r].terminate()
+    for r in pending:
+        try:
+            procs[r].wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+    text = procs[0].stdout.read() if procs[0].stdout else ""
+    if rc == 0:
+        out.write(text)
+        out.flush()
+    else:
+        sys.stderr.write(text)
+    return rc
 
 
 def timed_steps(run_step, pools, steps, warmup, sync):
@@ -114,10 +197,13 @@ class InputPool:
         return k, v
 
 
-def main():
-    args = parse_args()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
     # multi-process GPU work on this image needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, argv)          # plain `python bench.py --gpus N`: this process only launches
     import numpy as np
     import torch
 
@@ -125,9 +211,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+        args.gpus = world                            # under torch.distributed.run the environment decides
+    if world not in (1, 2, 4, 8):
+        raise SystemExit(f"bench.py: world size {world} is not 1, 2, 4 or 8")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     import lsdradixsort_amd as lsd
@@ -155,7 +241,8 @@ def main():
         lsd.set_tile_config(r, args.tile_config)
     if args.rank_method >= 0:
         lsd.set_rank_method(args.rank_method)
-    n = 1 << args.log2_keys
+    log2_keys, scaling = keys_per_gpu_log2(args, world)
+    n = 1 << log2_keys
     passes = 32 // r
 
     host_keys = mt19937_keys(n, rank)
@@ -195,12 +282,15 @@ def main():
         ok = bool((u[1:] >= u[:-1]).all()) if u.numel() > 1 else True
         if u.numel() and bits and args.partition == "msb":
             ok = ok and int(u[0].item()) >> (32 - bits) == rank and int(u[-1].item()) >> (32 - bits) == rank
+        ok = ok and backend.check_fault() == 0      # the workspace the sharded path's sorts actually ran in
         cnt = torch.tensor([u.numel(), 0 if ok else 1], dtype=torch.int64, device="cuda")
         dist.all_reduce(cnt)
         assert int(cnt[0].item()) == n * world and int(cnt[1].item()) == 0, "sharded sort failed its check"
         del res, u
-    check_status = lsd.lib().lsdsort_check_device(ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    assert check_status == 0, f"device fault word set ({check_status})"
+    else:
+        # `ws` is the workspace every timed sort ran in
+        check_status = lsd.lib().lsdsort_check_device(ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert check_status == 0, f"device fault word set ({check_status})"
 
     ms_per_step = elapsed / args.steps * 1e3
     total_keys = n * world
@@ -213,69 +303,116 @@ def main():
         assert bool((u[1:] >= u[:-1]).all()), "bench output is not sorted"
         del u
 
-    # ---- roofline of the dominant kernel (rank-and-scatter), measured live with hipEvents ----
-    roofline = None
-    stage_ms = None
-    if rank == 0:
+    def pmc_traffic(rb, pairs, nn):
+        """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_summary.json), with where it
+        came from: a builder's profiling run of the same kernel at the same n, NOT this run."""
+        prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        try:
+            e = json.load(open(prof)).get(f"rank_scatter_r{rb}{'_pairs' if pairs else ''}", {})
+            if e.get("n") == nn:
+                return e["hbm_bytes_per_launch"], (f"{e.get('source', 'profiles/pmc_summary.json')} (separate rocprofv3 --pmc passes, "
+                                                    f"kernel averaged {e.get('kernel_avg_us')} us in that run; not measured in this run)")
+        except Exception:
+            pass
+        return None, None
+
+    def measure_roofline(keys_t, vals_t, rb, pairs, nn, wsx, reps=5):
+        """The dominant kernel's own begin/end events (hipExtLaunchKernelGGL on the launch stream) over `reps` sorts."""
         scat, hist, scan, clear, totals = [], [], [], [], []
-        sort_tile_keys = None
-        for _ in range(5):
-            kv = pool.fresh()
-            tm = lsd.GPULSDRadixSortTimed(kv[0], r, d_vals=kv[1], algorithm=algo, workspace=ws)
-            sort_tile_keys = tm["tile_keys"]
+        tile = None
+        for _ in range(reps):
+            kk, vv = keys_t(), (vals_t() if pairs else None)
+            tm = lsd.GPULSDRadixSortTimed(kk, rb, d_vals=vv, algorithm=algo, workspace=wsx)
+            tile = tm["tile_keys"]
             scat += tm["scatter_ms"]
             hist.append(tm["histogram_ms"])
             scan.append(tm["scan_ms"])
             clear.append(tm["clear_ms"])
             totals.append(tm["total_ms"])
-        per_key = 16 if args.pairs else 8          # one read + one write of the key (and payload) per pass
+        per_key = 16 if pairs else 8               # one read + one write of the key (and payload) per pass
         scat_ms = float(np.mean(scat))
-        achieved = per_key * n / (scat_ms * 1e-3) / 1e9
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(prof):
-            try:
-                pj = json.load(open(prof))
-                key = f"rank_scatter_r{r}{'_pairs' if args.pairs else ''}"
-                if pj.get(key, {}).get("n") == n:
-                    traffic = pj[key]["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": "rank_scatter_kernel", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "algorithmic_bytes_per_launch": per_key * n,
-                    "launch_ms": round(scat_ms, 4)}
-        sort_bytes = (4 + 16 * passes) * n if args.pairs else 4 * (2 * passes + 1) * n
-        stage_ms = {"clear": round(float(np.mean(clear)), 4), "histogram": round(float(np.mean(hist)), 4),
-                    "scan": round(float(np.mean(scan)), 4), "scatter_per_pass": round(scat_ms, 4),
-                    "total_event": round(float(np.mean(totals)), 4),
-                    "sort_algorithmic_gbs": round(sort_bytes / (ms_per_step * 1e-3) / 1e9 / (world if distributed else 1), 1),
-                    "sort_roofline_frac": round(sort_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if not distributed else None}
+        achieved = per_key * nn / (scat_ms * 1e-3) / 1e9
+        traffic, source = pmc_traffic(rb, pairs, nn)
+        roof = {"bound": "hbm", "kernel": "rank_scatter_kernel", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_source": source, "algorithmic_bytes_per_launch": per_key * nn,
+                "launch_ms": round(scat_ms, 4)}
+        stages = {"clear": round(float(np.mean(clear)), 4), "histogram": round(float(np.mean(hist)), 4),
+                  "scan": round(float(np.mean(scan)), 4), "scatter_per_pass": round(scat_ms, 4),
+                  "total_event": round(float(np.mean(totals)), 4)}
+        return roof, stages, tile
 
-    # ---- secondary configs on the same box (N=1 only): configs[1] (r=4) and configs[4] (pairs) ----
+    # ---- roofline of the dominant kernel (rank-and-scatter), measured live with hipEvents ----
+    roofline = None
+    stage_ms = None
+    sort_tile_keys = None
+    if rank == 0:
+        roofline, stage_ms, sort_tile_keys = measure_roofline(lambda: pool.fresh()[0], lambda: pool.bufs[(pool.next - 1) % pool.capacity][1],
+                                                              r, args.pairs, n, ws)
+        sort_bytes = (4 + 16 * passes) * n if args.pairs else 4 * (2 * passes + 1) * n
+        stage_ms["sort_algorithmic_gbs"] = round(sort_bytes / (ms_per_step * 1e-3) / 1e9, 1) if not distributed else None
+        stage_ms["sort_roofline_frac"] = round(sort_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if not distributed else None
+        roofline["rank_method"] = lsd.rank_method(r)
+
+    # ---- secondary configs on the same box (N=1 only): configs[1] (r=4) and configs[4] (pairs), stage rows ----
     extra = {}
-    if rank == 0 and not distributed and not args.no_extra and not args.pairs and r == 8 and args.log2_keys == 28:
-        def quick(rb, pairs, nn):
-            kk = master[:nn].clone()
-            vv = torch.arange(nn, dtype=torch.int32, device="cuda") if pairs else None
+    if rank == 0 and not distributed and not args.no_extra and not args.pairs and r == 8 and log2_keys == 28:
+        def config_line(rb, pairs, nn, steps=8):
+            """The same measurement as the headline, on another BASELINE config: `steps` back-to-back sorts of fresh
+            copies between two synchronisations, then the kernel's own events for its roofline object."""
+            vals = torch.arange(nn, dtype=torch.int32, device="cuda") if pairs else None
             w2 = lsd.alloc_workspace(nn, rb, pairs, algo)
-            times = []
-            for i in range(6):
+            copies = [(master[:nn].clone(), vals.clone() if pairs else None) for _ in range(steps + 1)]
+            lsd.GPULSDRadixSort(copies[0][0], rb, d_vals=copies[0][1], algorithm=algo, workspace=w2)   # warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for kk, vv in copies[1:]:
+                lsd.GPULSDRadixSort(kk, rb, d_vals=vv, algorithm=algo, workspace=w2)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            it = iter(copies * 2)
+
+            def fresh_pair():
+                kk, vv = next(it)
                 kk.copy_(master[:nn])
                 if vv is not None:
-                    vv.copy_(torch.arange(nn, dtype=torch.int32, device="cuda"))
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                lsd.GPULSDRadixSort(kk, rb, d_vals=vv, algorithm=algo, workspace=w2)
-                torch.cuda.synchronize()
-                if i:
-                    times.append(time.perf_counter() - t0)
-            return nn / float(np.median(times)) / 1e6
-        extra["r4_256M_keys_mkeys_s"] = round(quick(4, False, n), 1)
-        extra["pairs_r8_128M_pairs_mpairs_s"] = round(quick(8, True, n // 2), 1)
+                    vv.copy_(vals)
+                fresh_pair.last = vv
+                return kk
+            roof, stages, tile = measure_roofline(fresh_pair, lambda: fresh_pair.last, rb, pairs, nn, w2, reps=3)
+            pp = 32 // rb
+            sort_bytes = (4 + 16 * pp) * nn if pairs else 4 * (2 * pp + 1) * nn
+            unit = "Mpairs/s" if pairs else "Mkeys/s"
+            return {"value": round(nn / (ms * 1e-3) / 1e6, 1), "unit": unit, "ms_per_step": round(ms, 4), "steps": steps,
+                    "n": nn, "radix_bits": rb, "pairs": pairs, "tile_keys": tile, "roofline": roof, "stages_ms": stages,
+                    "sort_algorithmic_bytes_per_item": sort_bytes // nn,
+                    "sort_roofline_frac": round(sort_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        extra["config2_r4_256M_keys"] = config_line(4, False, n)
+        extra["config5_pairs_r8_128M_pairs"] = config_line(8, True, n // 2)
+        extra["r4_256M_keys_mkeys_s"] = extra["config2_r4_256M_keys"]["value"]
+        extra["pairs_r8_128M_pairs_mpairs_s"] = extra["config5_pairs_r8_128M_pairs"]["value"]
+
+        # What the default rank form (one returning LDS add per key, probed on the device) buys over the
+        # architecture-guaranteed peer-mask form: the same sort with lsdsort_set_rank_method(0) and (2).
+        def method_ms(m, steps=4):
+            lsd.set_rank_method(m)
+            copies = [master.clone() for _ in range(steps + 1)]
+            lsd.GPULSDRadixSort(copies[0], r, algorithm=algo, workspace=ws)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for kk in copies[1:]:
+                lsd.GPULSDRadixSort(kk, r, algorithm=algo, workspace=ws)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3
+        ab0, ab2 = method_ms(0), method_ms(2)
+        lsd.set_rank_method(args.rank_method if args.rank_method >= 0 else -1)
+        extra["rank_method_ab"] = {"method_0_peer_mask_ms": round(ab0, 4), "method_2_lds_add_ms": round(ab2, 4),
+                                   "in_use": lsd.rank_method(r),
+                                   "opt_out": "lsdsort_set_rank_method(0) (include/lsdsort.h); method 2 is only used when the device probe passes"}
 
         # Stage micro-benchmarks (SURVEY section 8f.3): the counterparts of the reference's TestBuildHistogram
-        # (.cu:704) and TestGPUPrefixSum (.cu:304) harnesses, through the stage-level C-ABI entries.
+        # (.cu:704, sweep .cu:1123-1136) and TestGPUPrefixSum (.cu:304, sweep .cu:1083-1092) harnesses, through the
+        # stage-level C-ABI entries, for the reference's radix widths rs = {1, 2, 4, 8} (.cu:1055-1062).
         def time_stage(fn, reps=5):
             ts = []
             for i in range(reps + 1):
@@ -287,19 +424,21 @@ def main():
                 if i:
                     ts.append(e0.elapsed_time(e1))
             return float(np.median(ts))
-        hist_ms = time_stage(lambda: lsd.BuildHistograms(master, 8, 0))
-        h = lsd.BuildHistograms(master, 8, 0)
-        offs_ms = time_stage(lambda: lsd.BuildOffsets(h, 8))
+        stage = {}
+        for rb in (1, 2, 4, 8):
+            hist_ms = time_stage(lambda: lsd.BuildHistograms(master, rb, 0))
+            h = lsd.BuildHistograms(master, rb, 0)
+            offs_ms = time_stage(lambda: lsd.BuildOffsets(h, rb))
+            stage[f"tile_histograms_r{rb}"] = {"ms": round(hist_ms, 4), "read_gbs": round(4 * n / hist_ms / 1e6, 1),
+                                               "tile_keys": lsd.tile_keys(rb)}
+            stage[f"tile_offsets_r{rb}"] = {"ms": round(offs_ms, 4), "tiles": int(h.shape[0]),
+                                            "table_gbs": round(3 * 4 * h.numel() / offs_ms / 1e6, 1)}
+            del h
+        stage["replaces"] = ("tile_histograms: BuildHistogramsKernel .cu:660-702 (BenchmarkBuildHistogram.md rows); "
+                             "tile_offsets: offset construction .cu:862-895 (BenchmarkPrefixSum.md rows)")
         dh_ms = time_stage(lambda: lsd.DigitHistograms(master, 8))
-        extra["stage_bench"] = {
-            "tile_histograms_r8": {"ms": round(hist_ms, 4), "read_gbs": round(4 * n / hist_ms / 1e6, 1),
-                                   "replaces": "BuildHistogramsKernel .cu:660-702 (TestBuildHistogram .cu:704)"},
-            "tile_offsets_r8": {"ms": round(offs_ms, 4), "tiles": int(h.shape[0]),
-                                "table_gbs": round(3 * 4 * h.numel() / offs_ms / 1e6, 1),
-                                "replaces": "offset construction .cu:862-895 (TestGPUPrefixSum .cu:304)"},
-            "digit_histograms_all_passes_r8": {"ms": round(dh_ms, 4), "read_gbs": round(4 * n / dh_ms / 1e6, 1)},
-        }
-        del h
+        stage["digit_histograms_all_passes_r8"] = {"ms": round(dh_ms, 4), "read_gbs": round(4 * n / dh_ms / 1e6, 1)}
+        extra["stage_bench"] = stage
 
     # ---- CPU baseline: the reference's std::sort path on the host, one thread ----
     cpu_baseline = None
@@ -311,32 +450,45 @@ def main():
         sample = host_keys[:m]
         t_std = oracle.time_std_sort(sample)
         t_lsd = oracle.time_lsd_sort(sample, 8)
+        small = host_keys[:1 << 20]                  # BASELINE configs[0]: 1M keys, the reference's own CPU-runnable case
+        t_small = min(oracle.time_std_sort(small) for _ in range(3))
+        t_small_lsd = min(oracle.time_lsd_sort(small, 8) for _ in range(3))
         cpu_baseline = {"value": round(m / (t_std * 1e-3) / 1e6, 2), "unit": "Mkeys/s", "cores": 1, "kind": "port",
                         "sample": f"std::sort (LSDRadixSort.cu:97) of the first 2^{m.bit_length() - 1} keys of the "
-                                  f"workload, 1 thread, {t_std / 1e3:.1f} s; O(n log n), so the full 2^{args.log2_keys} "
+                                  f"workload, 1 thread, {t_std / 1e3:.1f} s; O(n log n), so the full 2^{log2_keys} "
                                   f"would be slower per key",
                         "lsd_r8_mkeys_s": round(m / (t_lsd * 1e-3) / 1e6, 2),
                         "lsd_r8_note": "restated reference CPU LSD (LSDRadixSort.cu:25-69), r=8, same sample",
+                        "config1_2p20_std_sort_mkeys_s": round(small.size / (t_small * 1e-3) / 1e6, 2),
+                        "config1_2p20_lsd_r8_mkeys_s": round(small.size / (t_small_lsd * 1e-3) / 1e6, 2),
+                        "config1_note": "BASELINE configs[0]: 2^20 keys, std::sort and the restated CPU LSD, 1 thread, best of 3",
                         "host_cpus": os.cpu_count()}
 
     if rank == 0:
-        workload = (f"2^{args.log2_keys} uniform uint32 {'key+payload pairs' if args.pairs else 'keys'} per GPU "
-                    f"(mt19937 seed=rank), {r}-bit radix, {passes} passes, {args.algorithm}"
-                    + (", MSB-bucket RCCL all-to-all + local sort" if distributed else ", device-resident"))
+        if distributed:
+            total_txt = f"2^{(n * world).bit_length() - 1} keys over {world} GPU{'s' if world > 1 else ''}" if (n * world) & (n * world - 1) == 0 else f"{n * world} keys"
+            workload = (f"{total_txt} = 2^{log2_keys} uniform uint32 keys per GPU (mt19937 seed=rank), "
+                        f"{'MSB-bucket' if args.partition == 'msb' else 'sampled-splitter'} partition + RCCL all-to-all over xGMI + "
+                        f"local {r}-bit LSD sort ({passes} passes) per step"
+                        + (" [BASELINE configs[3]]" if n * world == 1 << 30 and world == 8 else ""))
+        else:
+            workload = (f"2^{log2_keys} uniform uint32 {'key+payload pairs' if args.pairs else 'keys'} per GPU "
+                        f"(mt19937 seed=rank), {r}-bit radix, {passes} passes, {args.algorithm}, device-resident")
         line = {
             "metric": "Mkeys/s sorting uniform uint32, 1 GiB, 1/2/4/8 MI355X; % HBM roofline",
             "value": round(mkeys, 1), "unit": "Mkeys/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": workload, "keys_per_gpu": n, "radix_bits": r, "algorithm": args.algorithm,
-                       "pairs": bool(args.pairs), "tile_keys": sort_tile_keys},
+            "config": {"workload": workload, "keys_per_gpu": n, "total_keys": n * world, "radix_bits": r,
+                       "algorithm": args.algorithm, "pairs": bool(args.pairs), "tile_keys": sort_tile_keys},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "stages_ms": stage_ms, "extra": extra,
         }
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -86,12 +86,18 @@ def workspace_bytes(n: int, radix_bits: int = 8, pairs: bool = False, algorithm:
 
 
 def alloc_workspace(n: int, radix_bits: int = 8, pairs: bool = False, algorithm: int = LSDSORT_ALGO_ONESWEEP,
-                    device: str = "cuda"):
+                    device: str = "cuda", stream=None):
+    """Workspace tensor for a sort of up to ``n`` keys.  ``stream``: the stream the sort will run on when that is not
+    torch's current stream -- the block is then allocated under it, so the caching allocator orders its reuse
+    after the sort's kernels instead of after whatever the current stream is doing."""
     torch = _torch()
     nbytes = workspace_bytes(n, radix_bits, pairs, algorithm)
     if nbytes == 0 and n > 0:
         raise errors.LsdsortError(errors.LSDSORT_ERR_INVALID_ARG, "lsdsort_workspace_bytes_ex", "bad (n, radix_bits)")
     # torch's caching allocator returns 512-byte aligned blocks; the ABI needs 256.
+    if stream is not None:
+        with torch.cuda.stream(stream):
+            return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
     return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
 
 
@@ -137,7 +143,8 @@ def GPULSDRadixSort(d_keys, r: int = 8, d_vals=None, algorithm: int = LSDSORT_AL
         if d_vals.numel() != n:
             raise ValueError("keys and vals differ in length")
     if workspace is None:
-        workspace = alloc_workspace(n, r, pairs, algorithm, d_keys.device)
+        # the call returns while the passes are still running: a temporary workspace must belong to THEIR stream
+        workspace = alloc_workspace(n, r, pairs, algorithm, d_keys.device, stream=stream)
     st = lib().lsdsort_u32_device_ex(d_keys.data_ptr(), d_vals.data_ptr() if pairs else None, workspace.data_ptr(),
                                      workspace.numel(), n, r, algorithm, _stream(stream))
     check(st, "lsdsort_u32_device_ex")
@@ -164,7 +171,7 @@ def GPUSortTyped(d_keys, key_type: str = "int32", descending: bool = False, d_va
         if d_vals.numel() != n:
             raise ValueError("keys and vals differ in length")
     if workspace is None:
-        workspace = alloc_workspace(n, r, pairs, LSDSORT_ALGO_ONESWEEP, d_keys.device)
+        workspace = alloc_workspace(n, r, pairs, LSDSORT_ALGO_ONESWEEP, d_keys.device, stream=stream)
     check(lib().lsdsort_keys_device(d_keys.data_ptr(), d_vals.data_ptr() if pairs else None, workspace.data_ptr(),
                                     workspace.numel(), n, r, _KEY_TYPES[key_type], int(bool(descending)), _stream(stream)),
           "lsdsort_keys_device")
@@ -180,7 +187,7 @@ def GPULSDRadixSortTimed(d_keys, r: int = 8, d_vals=None, algorithm: int = LSDSO
     n = d_keys.numel()
     pairs = d_vals is not None
     if workspace is None:
-        workspace = alloc_workspace(n, r, pairs, algorithm, d_keys.device)
+        workspace = alloc_workspace(n, r, pairs, algorithm, d_keys.device, stream=stream)
     t = LsdsortTiming()
     st = lib().lsdsort_u32_device_timed(d_keys.data_ptr(), d_vals.data_ptr() if pairs else None, workspace.data_ptr(),
                                         workspace.numel(), n, r, algorithm, _stream(stream), ctypes.byref(t))

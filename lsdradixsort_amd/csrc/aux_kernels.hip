@@ -76,10 +76,11 @@ __global__ void __launch_bounds__(kHistThreads) digit_histograms_kernel(const ui
             }
         }
     }
-    // tail: the last (n mod chunk) keys, one per thread per step, by block 0
-    if (blockIdx.x == 0) {
+    // tail: the last (n mod chunk) keys -- or, for a base that is not 16-byte aligned (vec_chunks == 0: a
+    // slice of a larger buffer), every key -- one per thread per step, strided over the whole grid
+    {
         const uint32_t tail_begin = vec_chunks * (kHistThreads * 4);
-        for (uint32_t i = tail_begin + tid; i < n; i += kHistThreads) {
+        for (size_t i = (size_t)tail_begin + (size_t)blockIdx.x * kHistThreads + tid; i < n; i += (size_t)gridDim.x * kHistThreads) {
             const uint32_t k = keys[i];
 #pragma unroll
             for (int g = 0; g < G; g++) atomicAdd(&s_hist[(g * H + digit_at<R>(k, shift0 + g * R)) * C + copy], 1u);
@@ -98,10 +99,10 @@ template <int R, int G>
 static hipError_t launch_digit_histograms_inst(uint32_t shift0, const uint32_t* keys, uint32_t n, uint32_t* hist,
                                                hipStream_t stream)
 {
-    // 16-byte loads need a 16-byte aligned base; otherwise everything goes through the tail.
+    // 16-byte loads need a 16-byte aligned base; otherwise everything goes through the (grid-wide) scalar loop.
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const uint32_t vec_chunks = aligned ? n / (kHistThreads * 4) : 0;
-    uint32_t blocks = (vec_chunks + kHistVecPerThread - 1) / kHistVecPerThread;
+    uint32_t blocks = aligned ? (vec_chunks + kHistVecPerThread - 1) / kHistVecPerThread : (n + kHistThreads * 16 - 1) / (kHistThreads * 16);
     if (blocks > 2048) blocks = 2048;   // 256 CUs x 8: enough waves to cover HBM latency
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL((digit_histograms_kernel<R, G>), dim3(blocks), dim3(kHistThreads), 0, stream, keys, n, shift0,
@@ -142,9 +143,9 @@ __global__ void __launch_bounds__(kHistThreads) bucket_histogram_kernel(const ui
         count_key(v.z);
         count_key(v.w);
     }
-    if (blockIdx.x == 0) {
-        for (uint32_t i = vec_chunks * (kHistThreads * 4) + tid; i < n; i += kHistThreads) count_key(keys[i]);
-    }
+    for (size_t i = (size_t)vec_chunks * (kHistThreads * 4) + (size_t)blockIdx.x * kHistThreads + tid; i < n;
+         i += (size_t)gridDim.x * kHistThreads)
+        count_key(keys[i]);   // tail, or everything when the base is not 16-byte aligned
     __syncthreads();
     if (tid <= sp.count) {
         uint32_t sum = 0;
@@ -163,7 +164,8 @@ hipError_t launch_bucket_histogram(int bits, const uint32_t* splitters_host, con
     for (uint32_t i = 0; i < sp.count; i++) sp.value[i] = splitters_host[i];
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const uint32_t vec_chunks = aligned ? n / (kHistThreads * 4) : 0;
-    uint32_t blocks = vec_chunks < 2048 ? vec_chunks : 2048;
+    uint32_t blocks = aligned ? vec_chunks : (n + kHistThreads * 16 - 1) / (kHistThreads * 16);
+    if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(bucket_histogram_kernel, dim3(blocks), dim3(kHistThreads), 0, stream, keys, n, sp, hist, vec_chunks);
     return hipGetLastError();
@@ -420,10 +422,12 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
         for (int u = 0; u < VPT; u++) cur[u] = nxt[u];
         c = cn;
     }
-    if (blockIdx.x == 0) {
+    {
+        // tail -- or every key when the base is not 16-byte aligned (vec_chunks == 0) -- strided over the grid;
+        // a step's keys are consecutive, so a wave stays inside one pass-0 region except at a boundary
         const uint32_t tail_begin = vec_chunks * (THREADS * 4);
-        for (uint32_t i = tail_begin + tid; i < n; i += THREADS)
-            count_key_checked(xf.on ? to_sortable(keys[i], xf) : keys[i], i / region0_keys);
+        for (size_t i = (size_t)tail_begin + (size_t)blockIdx.x * THREADS + tid; i < n; i += (size_t)gridDim.x * THREADS)
+            count_key_checked(xf.on ? to_sortable(keys[i], xf) : keys[i], (uint32_t)(i / region0_keys));
     }
     __syncthreads();
     // Flush.  Pass 0's fields sit region-major in LDS: all 64 lanes of a wave share their position
@@ -482,7 +486,7 @@ static hipError_t launch_joint_inst(const uint32_t* keys, uint32_t n, uint32_t r
     if (region0_keys == 0 || region0_keys % (THREADS * 4) != 0) return hipErrorInvalidValue;
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const uint32_t vec_chunks = aligned ? n / (THREADS * 4) : 0;
-    uint32_t blocks = (vec_chunks + kHistVecPerThread - 1) / kHistVecPerThread;
+    uint32_t blocks = aligned ? (vec_chunks + kHistVecPerThread - 1) / kHistVecPerThread : (n + THREADS * 16 - 1) / (THREADS * 16);
     const uint32_t cap = (uint32_t)(2048 * 256 / THREADS);   // enough waves to cover HBM latency
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;

@@ -27,11 +27,6 @@ __device__ __forceinline__ constexpr uint32_t code_aggregate(uint32_t parity) { 
 __device__ __forceinline__ constexpr uint32_t code_prefix(uint32_t parity) { return parity ? 0u : 2u; }
 __device__ __forceinline__ constexpr uint32_t code_stale(uint32_t parity) { return parity ? 2u : 0u; }
 
-// Bounded spin: ~2^22 polls with a sleep in each is seconds of wall time, far beyond any
-// legitimate wait; on expiry the kernel raises the workspace's fault word and carries on so
-// the grid always drains (lsdsort_check_device reports it).
-constexpr uint32_t kSpinLimit = 1u << 22;
-
 __device__ __forceinline__ uint32_t load_status(const uint32_t* p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -75,6 +75,12 @@ __host__ __device__ inline uint32_t from_sortable(uint32_t t, const KeyTransform
 inline thread_local hipEvent_t t_launch_start = nullptr;
 inline thread_local hipEvent_t t_launch_stop = nullptr;
 
+// Bounded spin of the chained scan's look-back: ~2^22 empty polls with a sleep in each is seconds of wall
+// time, far beyond any legitimate wait.  On expiry the tile raises the workspace's fault word and gives
+// up -- it publishes no prefix and stores nothing -- and every other waiter, seeing the fault word, does
+// the same, so the grid always drains (lsdsort_check_device reports LSDSORT_ERR_DEVICE_FAULT).
+constexpr uint32_t kSpinLimit = 1u << 22;
+
 // Everything one rank-and-scatter launch needs.
 struct PassParams {
     const uint32_t* in;
@@ -93,6 +99,8 @@ struct PassParams {
     // staged form
     const uint32_t* global_off;  // [num_tiles][2^R] digit-major exclusive scan, block-major
     uint32_t* fault;             // workspace fault word
+    uint32_t spin_limit;         // empty look-back polls a tile sits out before it gives up (lsd_device.hpp kSpinLimit)
+    uint32_t mute_row;           // diagnostic builds only (LSD_FAULT_INJECT): status row + 1 that never publishes; 0 = none
     uint32_t xcd_chunk;          // staged form: consecutive tiles kept on one XCD (0 = no affinity)
     unsigned long long* stats;   // diagnostic builds only (LSD_PHASE_STATS); null otherwise
     // Splitter partition (narrow-digit kernels only, multi-GPU step 1 for skewed keys): when

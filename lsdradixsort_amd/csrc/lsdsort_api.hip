@@ -216,6 +216,8 @@ int check_device_ready(int* device_out = nullptr)
 
 std::atomic<uint32_t> g_xcd_chunk{16};   // consecutive tiles kept on one XCD
 std::atomic<unsigned long long*> g_stats{nullptr};   // diagnostic builds only
+std::atomic<uint32_t> g_spin_limit{lsd::kSpinLimit};   // empty look-back polls before a tile gives up
+std::atomic<uint32_t> g_mute_row{0};                   // diagnostic builds only (LSD_FAULT_INJECT)
 std::atomic<int> g_rank_setting{-1};   // -1 auto, 0 mask forms only, 2 returning LDS add wherever probed ok
 
 // The rank form a sort on `dev` with this radix will use.
@@ -342,6 +344,8 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
         p.shift = (uint32_t)(pass * radix_bits);
         p.num_tiles = L.tiles;
         p.fault = control;
+        p.spin_limit = g_spin_limit.load(std::memory_order_relaxed);
+        p.mute_row = g_mute_row.load(std::memory_order_relaxed);
         p.xcd_chunk = g_xcd_chunk.load(std::memory_order_relaxed);
         p.stats = g_stats.load(std::memory_order_relaxed);
         if (algorithm == LSDSORT_ALGO_ONESWEEP) {
@@ -517,6 +521,17 @@ int lsdsort_set_xcd_chunk(int chunk)
     g_xcd_chunk.store((uint32_t)chunk, std::memory_order_relaxed);
     return LSDSORT_OK;
 }
+
+#ifdef LSD_FAULT_INJECT
+// Diagnostic build only (make faultinject -> liblsdsort_faultinject.so, never the product): a small spin limit and a
+// status row that never publishes, so that a test can drive the bounded-wait expiry path (tests/test_fault_path.py).
+LSDSORT_API int lsdsort_debug_fault_inject(unsigned spin_limit, unsigned mute_row_plus_1)
+{
+    g_spin_limit.store(spin_limit ? spin_limit : lsd::kSpinLimit, std::memory_order_relaxed);
+    g_mute_row.store(mute_row_plus_1, std::memory_order_relaxed);
+    return LSDSORT_OK;
+}
+#endif
 
 #ifdef LSD_PHASE_STATS
 LSDSORT_API int lsdsort_debug_set_stats(unsigned long long* d_stats)
@@ -805,6 +820,7 @@ static int partition_impl(const uint32_t* d_in, uint32_t* d_out, size_t n, int m
         p.tickets = reinterpret_cast<uint32_t*>(ws + L.tickets);
         p.parity = 0;
         p.fault = control;
+        p.spin_limit = g_spin_limit.load(std::memory_order_relaxed);
         if (splitters) {
             p.num_splitters = (1u << msb_bits) - 1u;
             for (uint32_t i = 0; i < p.num_splitters; i++) p.splitters[i] = splitters[i];

@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             uint32_t xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             uint32_t got = 0xFFFFFFFFu;
+            s_misc[30] = 0;   // set by a digit thread whose look-back gives up (bounded spin, below)
             // home regions of this XCD first (spread over them by block index), then everyone else's
             constexpr uint32_t NREG = (uint32_t)regions_for_radix(R);
             constexpr uint32_t PER_XCD = NREG >= (uint32_t)kXcds ? NREG / (uint32_t)kXcds : 1u;
@@ -406,7 +407,14 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             for (int l = 0; l < LB; l++) window[l] = (j0 - l >= 0) ? load_status(status_col + (size_t)(j0 - l) * H) : c_stale;
         }
     };
-    if (CHAINED && tid < (uint32_t)H) {
+#ifdef LSD_FAULT_INJECT
+    // Diagnostic build only (make faultinject): the tile in status row mute_row - 1 never publishes, so its
+    // successors exercise the bounded-spin expiry below (tests/test_fault_path.py).
+    const bool muted = CHAINED && p.mute_row != 0 && tile + 1u == p.mute_row;
+#else
+    constexpr bool muted = false;
+#endif
+    if (CHAINED && tid < (uint32_t)H && !muted) {
         // publish as early as possible: successors can already add this tile's counts (behind the loads
         // above in issue order, so that their consumer need not outwait this store's acknowledgement)
         const uint32_t code = chain_pos == 0 ? c_prefix : code_aggregate(parity);
@@ -540,6 +548,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                             LSD_SET(15, __builtin_amdgcn_s_memrealtime());   // first (prefetched) step consumed
                         }
                         uint32_t spins = 0;
+                        bool gave_up = false;
                         while (!found) {
                             // further steps: LB rows at a time by the owner alone
 #pragma unroll
@@ -557,8 +566,13 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                             }
                             if (tid == 0) LSD_COUNT(7, 1);
                             if (consumed == 0) {
-                                if (++spins > kSpinLimit) {
+                                // Bounded wait.  On expiry: raise the fault word and give the tile up -- no prefix is
+                                // published from the partial sum and nothing of this tile is stored (below).  Every
+                                // waiter also looks at the fault word now and then, so once one tile has given up the
+                                // tiles behind it drain at once instead of each sitting out its own limit.
+                                if (++spins > p.spin_limit || ((spins & 255u) == 0u && load_status(p.fault) != 0u)) {
                                     atomicOr(p.fault, 1u);
+                                    gave_up = true;
                                     break;
                                 }
                                 __builtin_amdgcn_s_sleep(1);
@@ -571,7 +585,8 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                             LSD_SET(12, __builtin_amdgcn_s_memrealtime());
                             LSD_SET(13, j + 1);
                         }
-                        store_status(p.status + (size_t)tile * H + tid, ((excl + pub_total) << 2) | c_prefix);
+                        if (gave_up) s_misc[30] = 1u;
+                        else if (!muted) store_status(p.status + (size_t)tile * H + tid, ((excl + pub_total) << 2) | c_prefix);
                         if (tid == 0) LSD_SET(11, __builtin_amdgcn_s_memrealtime());
                     }
                     gbase = region_base + excl;
@@ -584,6 +599,8 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         lds_barrier();
         if (round == 0) LSD_STAMP(5);   // look-back (wave 0's digits) + barrier
         if (round == 0) clear_next();   // no load of this wave is waited for from here on
+        if (CHAINED && round == 0 && s_misc[30] != 0u) return;   // the look-back gave up (uniform): the sort has failed
+                                                               // (fault word set); store nothing from a base that is not known
 
         // linear read-back: consecutive threads hold consecutive tile positions, so each digit's
         // keys leave as one contiguous run

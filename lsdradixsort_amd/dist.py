@@ -58,6 +58,14 @@ class HipBackend:
 
         return torch.empty(n, dtype=ref.dtype, device=ref.device)
 
+    def check_fault(self) -> int:
+        """lsdsort_check_device on the workspace this backend's sorts ran in (0 = ok; synchronises the stream)."""
+        if self._ws is None:
+            return 0
+        import torch
+
+        return int(self._api.lib().lsdsort_check_device(self._ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
+
 
 @dataclass
 class ShardResult:

@@ -1,0 +1,85 @@
+"""Worker for tests/test_fault_path.py: runs in its own process with LSDSORT_LIB pointing at the diagnostic
+build liblsdsort_faultinject.so (make -C lsdradixsort_amd/csrc faultinject), never the product library.
+
+One status row is muted (its tile never publishes), the spin limit is small: the tiles behind it must give up
+-- fault word raised, grid drained, no prefix published from a partial sum, nothing stored from an unknown
+base -- and the sort after it, on the same workspace, must be clean again.  Prints one JSON line.
+"""
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+import lsdradixsort_amd as lsd
+
+assert "faultinject" in lsd.LIB_PATH, lsd.LIB_PATH
+L = lsd.lib()
+raw = ctypes.CDLL(lsd.LIB_PATH)
+raw.lsdsort_debug_fault_inject.argtypes = [ctypes.c_uint, ctypes.c_uint]
+raw.lsdsort_debug_fault_inject.restype = ctypes.c_int
+
+pairs = len(sys.argv) > 1 and sys.argv[1] == "pairs"
+r = 8
+n = (1 << 23) + 123
+GUARD = 1 << 16                     # int32 words on either side of the keys / bytes on either side of the workspace
+SENT = 0x7E7E7E7E
+rng = np.random.default_rng(5)
+host = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+
+
+def guarded_i32(fill):
+    big = torch.full((GUARD + n + GUARD,), SENT, dtype=torch.int32, device="cuda")
+    big[GUARD:GUARD + n] = fill
+    return big, big[GUARD:GUARD + n]
+
+
+kbig, keys = guarded_i32(torch.from_numpy(host.view(np.int32)).cuda())
+vbig, vals = guarded_i32(torch.arange(n, dtype=torch.int32, device="cuda")) if pairs else (None, None)
+wbytes = lsd.workspace_bytes(n, r, pairs)
+wbig = torch.full((GUARD + wbytes + GUARD,), 0x7E, dtype=torch.uint8, device="cuda")
+ws = wbig[GUARD:GUARD + wbytes]
+assert ws.data_ptr() % 256 == 0
+stream = torch.cuda.current_stream().cuda_stream
+
+
+def guards_intact():
+    ok = bool((kbig[:GUARD] == SENT).all()) and bool((kbig[GUARD + n:] == SENT).all())
+    ok = ok and bool((wbig[:GUARD] == 0x7E).all()) and bool((wbig[GUARD + wbytes:] == 0x7E).all())
+    if pairs:
+        ok = ok and bool((vbig[:GUARD] == SENT).all()) and bool((vbig[GUARD + n:] == SENT).all())
+    return ok
+
+
+out = {"pairs": pairs, "n": n}
+# --- 1. a muted tile in the middle of region 0's chain, small spin limit
+MUTED_ROW = 5
+raw.lsdsort_debug_fault_inject(4000, MUTED_ROW + 1)
+torch.cuda.synchronize()
+t0 = time.time()
+st = L.lsdsort_u32_device_ex(keys.data_ptr(), vals.data_ptr() if pairs else None, ws.data_ptr(), wbytes, n, r, 0, stream)
+out["launch_status"] = st
+out["check_status"] = L.lsdsort_check_device(ws.data_ptr(), stream)     # synchronises: the grid has drained
+out["drain_seconds"] = round(time.time() - t0, 3)
+out["guards_intact_after_fault"] = guards_intact()
+# --- 2. the same workspace, fault injection off: a clean sort
+raw.lsdsort_debug_fault_inject(0, 0)
+keys.copy_(torch.from_numpy(host.view(np.int32)).cuda())
+if pairs:
+    vals.copy_(torch.arange(n, dtype=torch.int32, device="cuda"))
+st2 = L.lsdsort_u32_device_ex(keys.data_ptr(), vals.data_ptr() if pairs else None, ws.data_ptr(), wbytes, n, r, 0, stream)
+out["second_status"] = st2
+out["second_check"] = L.lsdsort_check_device(ws.data_ptr(), stream)
+got = keys.cpu().numpy().view(np.uint32)
+out["second_sorted"] = bool(np.array_equal(got, np.sort(host)))
+if pairs:
+    order = np.argsort(host, kind="stable").astype(np.uint32)
+    out["second_payload_stable"] = bool(np.array_equal(vals.cpu().numpy().view(np.uint32), order))
+out["guards_intact_after_clean_sort"] = guards_intact()
+print(json.dumps(out), flush=True)

@@ -23,10 +23,20 @@ def _sort_dev(lsd, keys, r, algo=0, vals=None):
     return lsd.to_host(d), lsd.to_host(dv)
 
 
+@pytest.fixture(params=[-1, 0, 2], ids=["rank_auto", "rank_peer_mask", "rank_lds_add"])
+def rank_form(request, gpu):
+    """Every rank form the library can run (lsdsort_set_rank_method): the default picks the returning LDS add where
+    the device probe passed; 0 forces the architecture-guaranteed peer-mask forms (LDS OR at 8 bits, ballots at
+    4) that the library falls back to if the probe ever fails -- they must stay parity-green on their own."""
+    gpu.set_rank_method(request.param)
+    yield request.param
+    gpu.set_rank_method(-1)
+
+
 # ----------------------------------------------------------------------------- golden vectors
 @pytest.mark.parametrize("algo", list(ALGOS))
 @pytest.mark.parametrize("r", [1, 2, 4, 8])
-def test_golden_cases(gpu, golden, oracle_mod, algo, r):
+def test_golden_cases(gpu, golden, oracle_mod, algo, r, rank_form):
     for name in golden["case_names"]:
         keys, expect = golden[f"in__{name}"], golden[f"sorted__{name}"]
         got = _sort_dev(gpu, keys, r, ALGOS[algo])
@@ -97,7 +107,7 @@ def test_narrow_radix_vs_oracle(gpu, oracle_mod, r):
 
 
 @pytest.mark.parametrize("r", [4, 8])
-def test_distributions(gpu, oracle_mod, r):
+def test_distributions(gpu, oracle_mod, r, rank_form):
     n = (1 << 21) + 1234
     base = oracle_mod.mt19937_keys(n, 33)
     cases = {
@@ -150,7 +160,7 @@ def test_randomised_shapes_of_input(gpu, oracle_mod):
 
 
 @pytest.mark.parametrize("r", [4, 8])
-def test_pairs_vs_stable_sort(gpu, oracle_mod, r):
+def test_pairs_vs_stable_sort(gpu, oracle_mod, r, rank_form):
     n = (1 << 20) + 9
     keys = (oracle_mod.mt19937_keys(n, 41) % 1021).astype(np.uint32) * np.uint32(0x00400801)   # heavy duplicates
     vals = np.arange(n, dtype=np.uint32)
@@ -162,6 +172,53 @@ def test_pairs_vs_stable_sort(gpu, oracle_mod, r):
     # all keys equal: the payload must come back untouched
     k, v = _sort_dev(gpu, np.full(n, 7, dtype=np.uint32), r, 0, vals)
     assert np.array_equal(v, vals)
+
+
+@pytest.mark.parametrize("r", [8, 4, 1])
+@pytest.mark.parametrize("skip", [1, 2, 3])
+def test_keys_not_16_byte_aligned(gpu, oracle_mod, r, skip):
+    """A slice of a larger buffer (keys[skip:]): the upfront histogram's 16-byte loads do not apply, everything goes
+    through its scalar loop (grid-wide); the passes load 4 bytes per lane anyway."""
+    import torch
+
+    n = (1 << 20) + 4099
+    keys = oracle_mod.mt19937_keys(n + skip, 77 + skip)
+    whole = gpu.to_device(keys)
+    part = whole[skip:]
+    assert part.data_ptr() % 16 == 4 * skip and part.is_contiguous()
+    gpu.GPULSDRadixSort(part, r, check_fault=True)
+    got = gpu.to_host(whole)
+    assert np.array_equal(got[:skip], keys[:skip]), "keys in front of the slice were touched"
+    assert np.array_equal(got[skip:], np.sort(keys[skip:]))
+    # typed keys and the multi-GPU partition take the same histogram kernels
+    f = torch.from_numpy(keys.view(np.float32).copy()).cuda()[skip:]
+    f[torch.isnan(f)] = 0.0
+    ref = np.sort(f.cpu().numpy())
+    gpu.GPUSortTyped(f, "float32", r=8, check_fault=True)
+    assert np.array_equal(f.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    out, counts = gpu.MSBPartition(gpu.to_device(keys)[skip:], 2)
+    assert [int(c) for c in counts.cpu()] == [int(np.sum((keys[skip:] >> 30) == b)) for b in range(4)]
+    out, counts = gpu.SplitterPartition(gpu.to_device(keys)[skip:], [1 << 30, 1 << 31, 3 << 30])
+    assert [int(c) for c in counts.cpu()] == [int(np.sum((keys[skip:] >> 30) == b)) for b in range(4)]
+
+
+def test_temporary_workspace_belongs_to_the_sorts_stream(gpu, oracle_mod):
+    """No workspace given, explicit side stream: the temporary workspace is allocated under that stream,
+    so work queued on the current stream right after the call cannot be handed its block while the passes run."""
+    import torch
+
+    n = (1 << 22) + 17
+    keys = oracle_mod.mt19937_keys(n, 91)
+    side = torch.cuda.Stream()
+    for rep in range(4):
+        d = gpu.to_device(keys)
+        torch.cuda.synchronize()
+        gpu.GPULSDRadixSort(d, 8, stream=side)                 # returns while the passes are still running
+        junk = [torch.full((1 << 22,), 0x5A5A5A5A, dtype=torch.int32, device="cuda") for _ in range(8)]   # current stream
+        side.synchronize()
+        torch.cuda.synchronize()
+        assert np.array_equal(gpu.to_host(d), np.sort(keys)), rep
+        del junk
 
 
 def test_tile_configs(gpu, oracle_mod):
