@@ -262,12 +262,23 @@ def main(argv=None):
         def run_step(kv):
             lsd.GPULSDRadixSort(kv[0], r, d_vals=kv[1], algorithm=algo, workspace=ws)
     else:
-        from lsdradixsort_amd.dist import HipBackend, distributed_sort
+        from lsdradixsort_amd.dist import HipBackend, ShardedSorter, distributed_sort
 
-        backend = HipBackend(r)
+        if args.partition == "msb":
+            # the product path: the C++ step behind the C-ABI (lsdsort_sharded_u32_device), RCCL called from C++
+            backend = ShardedSorter(r)
+
+            def sharded(keys):
+                return backend.sort(keys)
+        else:
+            # skewed keys: sampled splitters, the torch.distributed driver over the same kernels
+            backend = HipBackend(r)
+
+            def sharded(keys):
+                return distributed_sort(keys, backend=backend, exchange_always=args.exercise_exchange, partition=args.partition)
 
         def run_step(kv):
-            distributed_sort(kv[0], backend=backend, exchange_always=args.exercise_exchange, partition=args.partition)
+            sharded(kv[0])
 
     elapsed = timed_steps(run_step, pool, args.steps, args.warmup, sync)
     if distributed:
@@ -276,7 +287,7 @@ def main(argv=None):
         elapsed = float(t.item())
         # correctness guard for the sharded path (untimed, collective): every rank's slice is sorted, lies
         # in its own MSB bucket, and the slices add up to every key
-        res = distributed_sort(pool.fresh()[0], backend=backend, exchange_always=args.exercise_exchange, partition=args.partition)
+        res = sharded(pool.fresh()[0])
         u = res.keys.to(torch.int64) & 0xFFFFFFFF
         bits = world.bit_length() - 1
         ok = bool((u[1:] >= u[:-1]).all()) if u.numel() > 1 else True
@@ -468,7 +479,7 @@ def main(argv=None):
         if distributed:
             total_txt = f"2^{(n * world).bit_length() - 1} keys over {world} GPU{'s' if world > 1 else ''}" if (n * world) & (n * world - 1) == 0 else f"{n * world} keys"
             workload = (f"{total_txt} = 2^{log2_keys} uniform uint32 keys per GPU (mt19937 seed=rank), "
-                        f"{'MSB-bucket' if args.partition == 'msb' else 'sampled-splitter'} partition + RCCL all-to-all over xGMI + "
+                        f"{'MSB-bucket partition + grouped ncclSend/ncclRecv (C++ step, lsdsort_sharded_u32_device)' if args.partition == 'msb' else 'sampled-splitter partition + torch.distributed all-to-all'} over xGMI + "
                         f"local {r}-bit LSD sort ({passes} passes) per step"
                         + (" [BASELINE configs[3]]" if n * world == 1 << 30 and world == 8 else ""))
         else:

@@ -37,8 +37,9 @@ typedef enum lsdsort_status {
     LSDSORT_ERR_HIP = -3,          /* a HIP runtime call failed; see lsdsort_last_hip_error()    */
     LSDSORT_ERR_WORKSPACE = -4,    /* workspace null, misaligned or smaller than required        */
     LSDSORT_ERR_TOO_LARGE = -5,    /* n above LSDSORT_MAX_KEYS                                   */
-    LSDSORT_ERR_UNSUPPORTED = -6,  /* valid request this build does not serve (e.g. num_gpus>1)  */
-    LSDSORT_ERR_DEVICE_FAULT = -7  /* a kernel reported a bounded-spin timeout (see below)       */
+    LSDSORT_ERR_UNSUPPORTED = -6,  /* valid request that cannot be served here (e.g. no librccl) */
+    LSDSORT_ERR_DEVICE_FAULT = -7, /* a kernel reported a bounded-spin timeout (see below)       */
+    LSDSORT_ERR_COMM = -8          /* an RCCL call failed; see lsdsort_last_comm_error()         */
 } lsdsort_status;
 
 /* Largest n any entry accepts: the chained tile prefix keeps 30 value bits per word.  The
@@ -65,9 +66,13 @@ typedef enum lsdsort_algorithm {
 LSDSORT_API int lsdsort_u32(uint32_t* keys, size_t n);
 
 /* Same with the radix width (1, 2, 4 or 8 -- the reference's sweep `rs`, .cu:1055-1062) and
- * a GPU count.  num_gpus must be 1: 0 (the "CPU path") returns LSDSORT_ERR_NO_DEVICE and
- * more than one GPU is served one-process-per-GPU by lsdsort_msb_partition_u32_device plus
- * the caller's RCCL communicator, so >1 returns LSDSORT_ERR_UNSUPPORTED. */
+ * a GPU count: num_gpus in {1, 2, 4, 8}.  0 (the "CPU path") returns
+ * LSDSORT_ERR_NO_DEVICE.  More than one GPU: this one process drives devices 0 .. num_gpus-1 (one host
+ * thread per device, one RCCL communicator made with ncclCommInitAll and kept for later calls): the array
+ * is cut into num_gpus shards, each device runs lsdsort_sharded_u32_device (below) on its shard, and the
+ * slices come back in rank order.  LSDSORT_ERR_NO_DEVICE if fewer gfx950 devices are visible,
+ * LSDSORT_ERR_UNSUPPORTED if librccl cannot be loaded.  The one-process-per-GPU form (bench.py, a
+ * torch.distributed or MPI launcher) uses the lsdsort_comm_* entries directly. */
 LSDSORT_API int lsdsort_u32_ex(uint32_t* keys, size_t n, int radix_bits, int num_gpus);
 
 /* Key/value form, stable by key (BASELINE.json configs[4]); no reference counterpart. */
@@ -187,6 +192,53 @@ LSDSORT_API int lsdsort_splitter_partition_u32_device(const uint32_t* d_in, uint
                                                       int log2_buckets, const uint32_t* splitters,
                                                       uint64_t* d_counts, void* d_workspace,
                                                       size_t workspace_bytes, void* hip_stream);
+
+/* ---- multi-GPU sort over RCCL / xGMI (BASELINE.json configs[3]) ------------------------ */
+/* New work: the reference is single-GPU.  Rank b of `world` (1, 2, 4 or 8) ends up
+ * owning every key whose top log2(world) bits equal b; the sorted array is the concatenation of the ranks'
+ * outputs in rank order.  One step per call, on the caller's stream:
+ *   1. histogram of the local keys' top bits                                    (one read)
+ *   2. stable partition of the shard by those bits  ||  on a side stream: ncclAllGather of the bucket
+ *      counts and capacities, count matrix to pinned host memory               (the only host wait)
+ *   3. ONE grouped ncclSend/ncclRecv exchange, every peer at once (all xGMI links busy; no ring),
+ *      the own bucket by a device copy
+ *   4. lsdsort_u32_device on what arrived.
+ * librccl is loaded on first use (dlopen); the rest of the library does not depend on it. */
+typedef struct lsdsort_comm lsdsort_comm;
+#define LSDSORT_COMM_ID_BYTES 128
+/* One-process-per-GPU bootstrap: rank 0 makes an id (ncclGetUniqueId), the launcher's own channel
+ * (torch.distributed, MPI, a file) carries its 128 bytes to every rank, every rank calls create with the HIP
+ * device it will sort on current.  Collective over the `world` ranks. */
+LSDSORT_API int lsdsort_comm_unique_id(void* id_out);
+LSDSORT_API int lsdsort_comm_create(const void* id, int world, int rank, lsdsort_comm** out);
+LSDSORT_API int lsdsort_comm_destroy(lsdsort_comm* comm);
+LSDSORT_API int lsdsort_comm_world(const lsdsort_comm* comm);
+LSDSORT_API int lsdsort_comm_rank(const lsdsort_comm* comm);
+/* Device workspace for a rank that contributes up to n_local_max keys and may receive up to out_capacity. */
+LSDSORT_API size_t lsdsort_sharded_workspace_bytes(size_t n_local_max, size_t out_capacity, int world, int radix_bits);
+/* The step.  d_keys_in (n_local keys, left untouched) and d_out (room for out_capacity keys) are device
+ * pointers on the communicator's device; on return *n_out keys of d_out are this rank's slice, *global_offset
+ * is the index of its first key in the global order, counts_matrix (may be NULL; world*world entries,
+ * [src][dst]) says who sent what.  Collective; blocks the host only for the count matrix (the exchange and
+ * the local sort stay queued on hip_stream).  If ANY rank would receive more than its out_capacity every rank
+ * returns LSDSORT_ERR_TOO_LARGE before the exchange (capacities travel with the counts), so nobody hangs. */
+LSDSORT_API int lsdsort_sharded_u32_device(lsdsort_comm* comm, const uint32_t* d_keys_in, size_t n_local,
+                                           uint32_t* d_out, size_t out_capacity, size_t* n_out,
+                                           uint64_t* global_offset, uint64_t* counts_matrix,
+                                           void* d_workspace, size_t workspace_bytes, int radix_bits,
+                                           void* hip_stream);
+/* After the stream has drained: the fault words of the step's two chained kernels sequences (partition pass, local
+ * sort) in a workspace last used with these sizes; LSDSORT_OK or LSDSORT_ERR_DEVICE_FAULT.  Synchronises hip_stream. */
+LSDSORT_API int lsdsort_sharded_check_device(void* d_workspace, size_t n_local, size_t out_capacity, int world,
+                                             int radix_bits, void* hip_stream);
+/* Host-side arithmetic of step 3, exported so that it can be checked without a GPU: from the world x world
+ * count matrix ([src][dst]) the element offsets of rank `rank`'s sends in its partitioned shard, of its
+ * receives in its output (source-rank order keeps the exchange stable), its output size and global offset.
+ * Returns LSDSORT_ERR_INVALID_ARG for a bad world / rank. */
+/* Text of the most recent failed RCCL call on this thread ("" if none). */
+LSDSORT_API const char* lsdsort_last_comm_error(void);
+LSDSORT_API int lsdsort_sharded_plan(const uint64_t* counts_matrix, int world, int rank, uint64_t* send_offsets,
+                                     uint64_t* recv_offsets, uint64_t* n_out, uint64_t* global_offset);
 
 /* ---- misc ----------------------------------------------------------------------------- */
 LSDSORT_API const char* lsdsort_strerror(int status);

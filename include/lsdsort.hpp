@@ -34,6 +34,9 @@ inline void check(int status, const char* where)
 inline void sort(uint32_t* keys, size_t n) { check(lsdsort_u32(keys, n), "lsdsort_u32"); }
 inline void sort(uint32_t* keys, size_t n, int radix_bits) { check(lsdsort_u32_ex(keys, n, radix_bits, 1), "lsdsort_u32_ex"); }
 
+// Host array over several GPUs of this node (one process; RCCL over xGMI; BASELINE.json configs[3]).
+inline void sort(uint32_t* keys, size_t n, int radix_bits, int num_gpus) { check(lsdsort_u32_ex(keys, n, radix_bits, num_gpus), "lsdsort_u32_ex"); }
+
 // Host key/value arrays, stable by key.
 inline void sort_pairs(uint32_t* keys, uint32_t* vals, size_t n) { check(lsdsort_pairs_u32(keys, vals, n), "lsdsort_pairs_u32"); }
 
@@ -70,5 +73,46 @@ inline void sort_device_descending(uint32_t* d_keys, void* d_workspace, size_t w
     check(lsdsort_keys_device(d_keys, d_vals, d_workspace, workspace_bytes_, n, radix_bits, LSDSORT_KEY_U32, 1, hip_stream),
           "lsdsort_keys_device");
 }
+
+// One rank of a multi-GPU sort (one process per GPU): RAII over lsdsort_comm_*.  Rank 0 calls unique_id() and ships
+// the 128 bytes to the other ranks over the launcher's own channel (MPI_Bcast, a file, torch.distributed).
+struct comm_id {
+    unsigned char bytes[LSDSORT_COMM_ID_BYTES];
+};
+inline comm_id unique_id()
+{
+    comm_id id;
+    check(lsdsort_comm_unique_id(id.bytes), "lsdsort_comm_unique_id");
+    return id;
+}
+class communicator {
+public:
+    communicator(const comm_id& id, int world, int rank) { check(lsdsort_comm_create(id.bytes, world, rank, &c_), "lsdsort_comm_create"); }
+    ~communicator() { lsdsort_comm_destroy(c_); }
+    communicator(const communicator&) = delete;
+    communicator& operator=(const communicator&) = delete;
+    int world() const { return lsdsort_comm_world(c_); }
+    int rank() const { return lsdsort_comm_rank(c_); }
+    size_t workspace_bytes(size_t n_local_max, size_t out_capacity, int radix_bits = 8) const
+    {
+        return lsdsort_sharded_workspace_bytes(n_local_max, out_capacity, world(), radix_bits);
+    }
+    struct slice {
+        size_t n;                 // keys of d_out that are this rank's part of the result
+        uint64_t global_offset;   // index of the first of them in the global order
+    };
+    // Collective.  d_keys_in is left untouched; the exchange and the local sort stay queued on hip_stream.
+    slice sort_device(const uint32_t* d_keys_in, size_t n_local, uint32_t* d_out, size_t out_capacity, void* d_workspace,
+                      size_t workspace_bytes_, int radix_bits = 8, void* hip_stream = nullptr, uint64_t* counts_matrix = nullptr)
+    {
+        slice s{0, 0};
+        check(lsdsort_sharded_u32_device(c_, d_keys_in, n_local, d_out, out_capacity, &s.n, &s.global_offset, counts_matrix,
+                                         d_workspace, workspace_bytes_, radix_bits, hip_stream), "lsdsort_sharded_u32_device");
+        return s;
+    }
+
+private:
+    lsdsort_comm* c_ = nullptr;
+};
 
 }  // namespace lsd

@@ -60,6 +60,20 @@ SIGNATURES = {
                                                  c_size, ctypes.c_void_p]),
     "lsdsort_splitter_partition_u32_device": (c_int, [c_u32p, c_u32p, c_size, c_int, ctypes.POINTER(ctypes.c_uint32),
                                                       ctypes.c_void_p, ctypes.c_void_p, c_size, ctypes.c_void_p]),
+    "lsdsort_comm_unique_id": (c_int, [ctypes.c_void_p]),
+    "lsdsort_comm_create": (c_int, [ctypes.c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "lsdsort_comm_destroy": (c_int, [ctypes.c_void_p]),
+    "lsdsort_comm_world": (c_int, [ctypes.c_void_p]),
+    "lsdsort_comm_rank": (c_int, [ctypes.c_void_p]),
+    "lsdsort_sharded_workspace_bytes": (c_size, [c_size, c_size, c_int, c_int]),
+    "lsdsort_sharded_u32_device": (c_int, [ctypes.c_void_p, c_u32p, c_size, c_u32p, c_size, ctypes.POINTER(c_size),
+                                           ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p,
+                                           c_size, c_int, ctypes.c_void_p]),
+    "lsdsort_sharded_check_device": (c_int, [ctypes.c_void_p, c_size, c_size, c_int, c_int, ctypes.c_void_p]),
+    "lsdsort_sharded_plan": (c_int, [ctypes.POINTER(ctypes.c_uint64), c_int, c_int, ctypes.POINTER(ctypes.c_uint64),
+                                     ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                                     ctypes.POINTER(ctypes.c_uint64)]),
+    "lsdsort_last_comm_error": (ctypes.c_char_p, []),
     "lsdsort_strerror": (ctypes.c_char_p, [c_int]),
     "lsdsort_last_hip_error": (c_int, []),
     "lsdsort_last_hip_error_string": (ctypes.c_char_p, []),

@@ -454,6 +454,12 @@ MsbLayout make_msb_layout(size_t n, int msb_bits)
 
 }  // namespace
 
+// internals other translation units of the library use (sharded.hip)
+namespace lsd {
+int sort_host_multi(uint32_t* keys, size_t n, int radix_bits, int num_gpus);   // sharded.hip
+void set_last_hip_error(hipError_t e) { g_last_hip = e; }
+}  // namespace lsd
+
 // =============================================================================== C-ABI
 extern "C" {
 
@@ -466,8 +472,9 @@ const char* lsdsort_strerror(int status)
         case LSDSORT_ERR_HIP: return "HIP runtime error (see lsdsort_last_hip_error_string)";
         case LSDSORT_ERR_WORKSPACE: return "workspace null, not 256-byte aligned, or too small";
         case LSDSORT_ERR_TOO_LARGE: return "n exceeds LSDSORT_MAX_KEYS";
-        case LSDSORT_ERR_UNSUPPORTED: return "unsupported request (multi-GPU runs one process per GPU; see INTEGRATION.md)";
+        case LSDSORT_ERR_UNSUPPORTED: return "unsupported request (typed keys need radix 4 or 8; multi-GPU needs librccl)";
         case LSDSORT_ERR_DEVICE_FAULT: return "a kernel gave up a bounded wait; output undefined";
+        case LSDSORT_ERR_COMM: return "RCCL call failed (see lsdsort_last_comm_error)";
         default: return "unknown lsdsort status";
     }
 }
@@ -681,7 +688,7 @@ int lsdsort_u32_ex(uint32_t* keys, size_t n, int radix_bits, int num_gpus)
 {
     if (num_gpus == 0) return LSDSORT_ERR_NO_DEVICE;     // the CPU path is the oracle, not the product
     if (num_gpus < 0) return LSDSORT_ERR_INVALID_ARG;
-    if (num_gpus > 1) return LSDSORT_ERR_UNSUPPORTED;    // one process per GPU: lsdsort_msb_partition_u32_device + RCCL
+    if (num_gpus > 1) return lsd::sort_host_multi(keys, n, radix_bits, num_gpus);   // sharded.hip: one thread per device, RCCL
     return sort_host(keys, nullptr, n, radix_bits);
 }
 
@@ -775,7 +782,8 @@ size_t lsdsort_msb_partition_workspace_bytes(size_t n, int msb_bits)
 // Stable partition into 2^msb_bits buckets: by the top msb_bits key bits (splitters == nullptr) or by
 // 2^msb_bits - 1 ascending splitters (bucket = number of splitters <= key).
 static int partition_impl(const uint32_t* d_in, uint32_t* d_out, size_t n, int msb_bits, const uint32_t* splitters,
-                          uint64_t* d_counts, void* d_workspace, size_t workspace_bytes, void* hip_stream)
+                          uint64_t* d_counts, void* d_workspace, size_t workspace_bytes, void* hip_stream,
+                          hipEvent_t counts_ready = nullptr)
 {
     if (msb_bits < 0 || msb_bits > 3 || !d_counts) return LSDSORT_ERR_INVALID_ARG;
     if (splitters)
@@ -797,8 +805,9 @@ static int partition_impl(const uint32_t* d_in, uint32_t* d_out, size_t n, int m
     LSD_HIP(hipMemsetAsync(ws, 0, L.zero_bytes, stream));
     if (msb_bits == 0) {
         // one bucket: the shard itself
-        if (n) LSD_HIP(hipMemcpyAsync(d_out, d_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
         LSD_HIP(lsd::launch_store_u64(d_counts, (uint64_t)n, stream));
+        if (counts_ready) LSD_HIP(hipEventRecord(counts_ready, stream));
+        if (n) LSD_HIP(hipMemcpyAsync(d_out, d_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
         return LSDSORT_OK;
     }
     if (n) {
@@ -809,6 +818,10 @@ static int partition_impl(const uint32_t* d_in, uint32_t* d_out, size_t n, int m
         else
             LSD_HIP(lsd::launch_digit_histograms(msb_bits, 1, shift, d_in, (uint32_t)n, hist, stream));
         LSD_HIP(lsd::launch_scan_regions(msb_bits, 1, 1, hist, (uint32_t)n, (uint32_t)shape->tile(), 0, table, stream));
+        // the bucket sizes are final here: hand them out before the partition pass, so that a caller's count
+        // exchange (multi-GPU step, sharded.hip) runs beside it
+        LSD_HIP(lsd::launch_widen_counts(hist, d_counts, bins, stream));
+        if (counts_ready) LSD_HIP(hipEventRecord(counts_ready, stream));
         PassParams p{};
         p.in = d_in;
         p.out = d_out;
@@ -826,10 +839,23 @@ static int partition_impl(const uint32_t* d_in, uint32_t* d_out, size_t n, int m
             for (uint32_t i = 0; i < p.num_splitters; i++) p.splitters[i] = splitters[i];
         }
         LSD_HIP(lsd::launch_rank_scatter(msb_bits, *shape, resolve_rank_method(dev, msb_bits), true, p, stream));
+    } else {
+        LSD_HIP(lsd::launch_widen_counts(hist, d_counts, bins, stream));   // all zero
+        if (counts_ready) LSD_HIP(hipEventRecord(counts_ready, stream));
     }
-    LSD_HIP(lsd::launch_widen_counts(hist, d_counts, bins, stream));
     return LSDSORT_OK;
 }
+
+}  // extern "C"
+namespace lsd {
+// the MSB partition with its bucket counts published (and `counts_ready` recorded) BEFORE the partition pass
+int partition_with_event(const uint32_t* d_in, uint32_t* d_out, size_t n, int msb_bits, uint64_t* d_counts,
+                         void* d_workspace, size_t workspace_bytes, hipStream_t stream, hipEvent_t counts_ready)
+{
+    return partition_impl(d_in, d_out, n, msb_bits, nullptr, d_counts, d_workspace, workspace_bytes, stream, counts_ready);
+}
+}  // namespace lsd
+extern "C" {
 
 int lsdsort_msb_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size_t n, int msb_bits,
                                      uint64_t* d_counts, void* d_workspace, size_t workspace_bytes, void* hip_stream)

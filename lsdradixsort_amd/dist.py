@@ -11,11 +11,19 @@ equal b -- with exactly ONE exchange step:
                                                      xGMI links are busy; no ring)
   4. local LSD sort of what arrived                  lsdsort_u32_device (HIP)
 
-The globally sorted array is the concatenation of the ranks' results in rank order.  All
-compute is in liblsdsort.so; ``torch.distributed`` is only the transport.  The compute calls
-go through a small backend object so the exchange logic can be exercised on CPU tensors with
-``gloo`` in tests (tests inject an oracle-backed backend; the product default is HIP and there
-is no other in this package).
+The globally sorted array is the concatenation of the ranks' results in rank order.
+
+Two drivers of the same step live here:
+
+* ``ShardedSorter`` -- the product path: a thin face over the C++ step behind the C-ABI
+  (``lsdsort_comm_*`` / ``lsdsort_sharded_u32_device``, lsdradixsort_amd/csrc/sharded.hip), which
+  talks to RCCL itself (grouped ncclSend/ncclRecv on the sort's stream, the count exchange on a
+  side stream while the partition pass runs).  ``torch.distributed`` only carries the 128-byte
+  RCCL id at set-up.  This is what ``bench.py --gpus N`` times.
+* ``distributed_sort`` -- the same step written against ``torch.distributed`` collectives, with the
+  compute calls behind a small backend object, so that the exchange logic (and the sampled-
+  splitter partition for skewed keys) can be exercised on CPU tensors with ``gloo`` in tests
+  (tests inject an oracle-backed backend; the package itself has only the HIP backend).
 """
 from __future__ import annotations
 
@@ -72,6 +80,106 @@ class ShardResult:
     keys: object            # this rank's slice of the globally sorted array (torch tensor)
     global_offset: int      # index of keys[0] in the global order
     counts: object          # world x world int64 matrix: counts[src][dst] = keys src sent to dst
+
+
+class ShardedSorter:
+    """One rank of the multi-GPU sort through the C++ step (MSB buckets).  Collective construction: rank 0 makes
+    the RCCL id, ``torch.distributed`` (any backend) broadcasts its 128 bytes, every rank creates its communicator
+    on its current CUDA/HIP device.  Without an initialised process group it is a world of one (the RCCL calls
+    are still made: a one-GPU box rehearses the whole path)."""
+
+    def __init__(self, radix_bits: int = 8, group=None, slack: float = 0.25):
+        import ctypes
+
+        import torch
+        import torch.distributed as dist
+
+        from . import api
+        from .errors import check
+
+        self._api, self._ctypes, self._check = api, ctypes, check
+        self.radix_bits = radix_bits
+        self.slack = slack
+        self.group = group
+        live = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if live else 1
+        self.rank = dist.get_rank(group) if live else 0
+        _log2_exact(self.world)
+        L = api.lib()
+        ident = (ctypes.c_ubyte * 128)()
+        if self.rank == 0:
+            check(L.lsdsort_comm_unique_id(ident), "lsdsort_comm_unique_id")
+        if self.world > 1:
+            on_gpu = dist.get_backend(group) == "nccl"
+            t = torch.tensor(list(ident), dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = (ctypes.c_ubyte * 128)(*[int(x) for x in t.cpu()])
+        handle = ctypes.c_void_p()
+        check(L.lsdsort_comm_create(ident, self.world, self.rank, ctypes.byref(handle)), "lsdsort_comm_create")
+        self._comm = handle
+        self._ws = None
+        self._out = None
+        self._last = None
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self._api.lib().lsdsort_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _buffers(self, n_local: int, capacity: int, device):
+        import torch
+
+        L = self._api.lib()
+        need = int(L.lsdsort_sharded_workspace_bytes(n_local, capacity, self.world, self.radix_bits))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
+        if self._out is None or self._out.numel() < capacity:
+            self._out = torch.empty(max(capacity, 1), dtype=torch.int32, device=device)
+        return self._ws, self._out
+
+    def sort(self, local_keys, capacity: int | None = None) -> "ShardResult":
+        """Sort the union of every rank's ``local_keys`` (int32 CUDA tensors of uint32 bit patterns, left untouched);
+        returns this rank's slice -- a view into a buffer the sorter owns and reuses on the next call.  Collective.
+        ``capacity``: keys this rank can receive (default: its own share plus ``slack``); if any rank's is too small
+        every rank learns it before the exchange and the step is repeated once with exact sizes."""
+        import torch
+
+        ctypes = self._ctypes
+        L = self._api.lib()
+        n_local = local_keys.numel()
+        stream = torch.cuda.current_stream().cuda_stream
+        cap = capacity if capacity is not None else int(n_local * (1.0 + self.slack)) + 4096
+        for attempt in (0, 1):
+            ws, out = self._buffers(n_local, cap, local_keys.device)
+            n_out = ctypes.c_size_t(0)
+            offset = ctypes.c_uint64(0)
+            matrix = (ctypes.c_uint64 * (self.world * self.world))()
+            st = L.lsdsort_sharded_u32_device(self._comm, local_keys.data_ptr(), n_local, out.data_ptr(), cap, ctypes.byref(n_out),
+                                              ctypes.byref(offset), matrix, ws.data_ptr(), ws.numel(), self.radix_bits, stream)
+            if st == -5 and attempt == 0:            # LSDSORT_ERR_TOO_LARGE on EVERY rank (skewed keys): exact sizes this time
+                cap = max(int(n_out.value), 1)
+                continue
+            self._check(st, "lsdsort_sharded_u32_device")
+            self._last = (n_local, cap)
+            break
+        counts = torch.tensor(list(matrix), dtype=torch.int64).view(self.world, self.world)
+        return ShardResult(out[: n_out.value], int(offset.value), counts)
+
+    def check_fault(self) -> int:
+        """Fault words of the last step's partition pass and local sort (0 = ok; synchronises the stream)."""
+        import torch
+
+        if self._ws is None or getattr(self, "_last", None) is None:
+            return 0
+        n_local, cap = self._last
+        return int(self._api.lib().lsdsort_sharded_check_device(self._ws.data_ptr(), n_local, cap, self.world, self.radix_bits,
+                                                                torch.cuda.current_stream().cuda_stream))
 
 
 SAMPLES_PER_RANK = 4096

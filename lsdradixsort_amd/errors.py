@@ -9,6 +9,7 @@ LSDSORT_ERR_WORKSPACE = -4
 LSDSORT_ERR_TOO_LARGE = -5
 LSDSORT_ERR_UNSUPPORTED = -6
 LSDSORT_ERR_DEVICE_FAULT = -7
+LSDSORT_ERR_COMM = -8
 
 LSDSORT_ALGO_ONESWEEP = 0
 LSDSORT_ALGO_STAGED = 1
@@ -33,4 +34,6 @@ def check(status: int, where: str) -> None:
         detail = L.lsdsort_strerror(status).decode()
         if status == LSDSORT_ERR_HIP:
             detail += f" [{L.lsdsort_last_hip_error()}: {L.lsdsort_last_hip_error_string().decode()}]"
+        if status == LSDSORT_ERR_COMM:
+            detail += f" [{L.lsdsort_last_comm_error().decode()}]"
         raise LsdsortError(status, where, detail)

@@ -57,7 +57,8 @@ def test_argument_validation_needs_no_device():
     assert L.lsdsort_u32_ex(a.ctypes.data, 8, 7, 1) == errors.LSDSORT_ERR_INVALID_ARG
     assert L.lsdsort_u32_ex(a.ctypes.data, 8, 16, 1) == errors.LSDSORT_ERR_INVALID_ARG   # reference rejects r > 10 too (.cu:953)
     assert L.lsdsort_u32_ex(a.ctypes.data, 8, 8, 0) == errors.LSDSORT_ERR_NO_DEVICE      # no CPU path in the product
-    assert L.lsdsort_u32_ex(a.ctypes.data, 8, 8, 8) == errors.LSDSORT_ERR_UNSUPPORTED
+    assert L.lsdsort_u32_ex(a.ctypes.data, 8, 8, 8) == errors.LSDSORT_ERR_NO_DEVICE        # 8 GPUs asked for, none here
+    assert L.lsdsort_u32_ex(a.ctypes.data, 8, 8, 3) == errors.LSDSORT_ERR_INVALID_ARG      # MSB buckets: 1, 2, 4 or 8
     assert L.lsdsort_u32_ex(a.ctypes.data, 8, 8, -1) == errors.LSDSORT_ERR_INVALID_ARG
     assert L.lsdsort_u32(None, 5) == errors.LSDSORT_ERR_INVALID_ARG
     assert L.lsdsort_pairs_u32(a.ctypes.data, None, 8) == errors.LSDSORT_ERR_INVALID_ARG

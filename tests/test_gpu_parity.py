@@ -476,6 +476,33 @@ def test_rccl_exchange_path_world_of_one(gpu, oracle_mod):
         dist.destroy_process_group()
 
 
+def test_cpp_sharded_step_world_of_one(gpu, oracle_mod):
+    """The product's multi-GPU step (ShardedSorter -> lsdsort_sharded_u32_device, C++ over RCCL) as a world of one:
+    ncclGetUniqueId / ncclCommInitRank / ncclAllGather on the side stream / the (empty) grouped exchange / own-bucket
+    copy / local sort, several steps on one communicator, ragged and empty shards, and the capacity retry."""
+    import torch
+    from lsdradixsort_amd.dist import ShardedSorter
+
+    sorter = ShardedSorter(8)
+    try:
+        assert sorter.world == 1 and sorter.rank == 0
+        for n, seed in (((1 << 20) + 3, 5), ((1 << 22) + 12345, 6), (1, 7), (0, 8), ((1 << 23) + 1, 9)):
+            keys = oracle_mod.mt19937_keys(n, seed)
+            d = gpu.to_device(keys)
+            res = sorter.sort(d)
+            torch.cuda.synchronize()
+            assert res.global_offset == 0 and int(res.counts.sum()) == n and res.keys.numel() == n
+            assert np.array_equal(gpu.to_host(res.keys), np.sort(keys)), n
+            assert np.array_equal(gpu.to_host(d), keys), "the input shard is left untouched"
+            assert sorter.check_fault() == 0
+        # a capacity that is too small: every rank hears LSDSORT_ERR_TOO_LARGE before the exchange; the face retries once
+        keys = oracle_mod.mt19937_keys((1 << 20) + 9, 10)
+        res = sorter.sort(gpu.to_device(keys), capacity=1000)
+        assert np.array_equal(gpu.to_host(res.keys), np.sort(keys))
+    finally:
+        sorter.close()
+
+
 @pytest.mark.parametrize("nsplit", [0, 1, 3, 7])
 def test_splitter_partition(gpu, oracle_mod, nsplit):
     """Partition by value (multi-GPU step 1 for skewed keys): bucket = number of splitters <= key, stable,
