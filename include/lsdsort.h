@@ -62,8 +62,12 @@ typedef enum lsdsort_algorithm {
 
 /* sort(uint32_t* keys, size_t n) of BASELINE.json's north_star: host pointer, in place,
  * ascending.  Replaces the alloc / H2D / GPULSDRadixSort / D2H sequence of
- * TestGPULSDRadixSort, .cu:966-1005.  Blocking.  radix 8, current HIP device. */
+ * TestGPULSDRadixSort, .cu:966-1005.  Blocking.  radix 8, current HIP device.
+ * The input crosses PCIe in 64 MiB chunks with the upfront histogram of each chunk running behind it; the
+ * device buffers and workspace are kept per device between calls (the reference allocates and frees around
+ * every sort) -- lsdsort_release_host_cache() frees them; calls on one device take turns. */
 LSDSORT_API int lsdsort_u32(uint32_t* keys, size_t n);
+LSDSORT_API int lsdsort_release_host_cache(void);
 
 /* Same with the radix width (1, 2, 4 or 8 -- the reference's sweep `rs`, .cu:1055-1062) and
  * a GPU count: num_gpus in {1, 2, 4, 8}.  0 (the "CPU path") returns
@@ -115,6 +119,24 @@ LSDSORT_API int lsdsort_u32_device_ex(uint32_t* d_keys, uint32_t* d_vals, void* 
 typedef enum lsdsort_key_type { LSDSORT_KEY_U32 = 0, LSDSORT_KEY_I32 = 1, LSDSORT_KEY_F32 = 2 } lsdsort_key_type;
 LSDSORT_API int lsdsort_keys_device(void* d_keys, uint32_t* d_vals, void* d_workspace, size_t workspace_bytes,
                                     size_t n, int radix_bits, int key_type, int descending, void* hip_stream);
+
+/* 64-bit keys and 64-bit payloads (no reference counterpart, .cu:62), built on the 32-bit
+ * pass kernels: an LSD sort on a 64-bit key is an LSD sort on its low word followed by a stable one on its
+ * high word (lsdradixsort_amd/csrc/wide.hip).  Device pointers, in place, stream-ordered, nothing allocated.
+ *   lsdsort_u64_device     : uint64 keys only.  Split into words, two key/value sorts (each word once the key,
+ *                            once the payload), merge: 8 passes at radix 8, 16 B/key/pass.
+ *   lsdsort_records_device : keys of key_bits (32 | 64) with payloads of val_bits (32 | 64; 32/32 is
+ *                            lsdsort_pairs_u32_device), stable by key: an index rides through the sorts and the
+ *                            records are gathered once at the end.
+ * lsdsort_wide_workspace_bytes(n, radix_bits, key_bits, val_bits) sizes the workspace (val_bits 0 = keys only);
+ * lsdsort_wide_check_device reads the fault word of the sorts inside it (like lsdsort_check_device). */
+LSDSORT_API size_t lsdsort_wide_workspace_bytes(size_t n, int radix_bits, int key_bits, int val_bits);
+LSDSORT_API int lsdsort_u64_device(uint64_t* d_keys, void* d_workspace, size_t workspace_bytes, size_t n,
+                                   int radix_bits, void* hip_stream);
+LSDSORT_API int lsdsort_records_device(void* d_keys, void* d_vals, int key_bits, int val_bits, void* d_workspace,
+                                       size_t workspace_bytes, size_t n, int radix_bits, void* hip_stream);
+LSDSORT_API int lsdsort_wide_check_device(void* d_workspace, size_t n, int radix_bits, int key_bits, int val_bits,
+                                          void* hip_stream);
 
 /* After the stream has drained: LSDSORT_OK, or LSDSORT_ERR_DEVICE_FAULT if a kernel of the
  * last sort on this workspace gave up a bounded spin (never expected; the output is then

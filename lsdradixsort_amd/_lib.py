@@ -39,12 +39,18 @@ SIGNATURES = {
     "lsdsort_u32": (c_int, [c_u32p, c_size]),
     "lsdsort_u32_ex": (c_int, [c_u32p, c_size, c_int, c_int]),
     "lsdsort_pairs_u32": (c_int, [c_u32p, c_u32p, c_size]),
+    "lsdsort_release_host_cache": (c_int, []),
     "lsdsort_workspace_bytes": (c_size, [c_size, c_int, c_int]),
     "lsdsort_workspace_bytes_ex": (c_size, [c_size, c_int, c_int, c_int]),
     "lsdsort_u32_device": (c_int, [c_u32p, ctypes.c_void_p, c_size, c_size, c_int, ctypes.c_void_p]),
     "lsdsort_pairs_u32_device": (c_int, [c_u32p, c_u32p, ctypes.c_void_p, c_size, c_size, c_int, ctypes.c_void_p]),
     "lsdsort_u32_device_ex": (c_int, [c_u32p, c_u32p, ctypes.c_void_p, c_size, c_size, c_int, c_int, ctypes.c_void_p]),
     "lsdsort_keys_device": (c_int, [ctypes.c_void_p, c_u32p, ctypes.c_void_p, c_size, c_size, c_int, c_int, c_int, ctypes.c_void_p]),
+    "lsdsort_wide_workspace_bytes": (c_size, [c_size, c_int, c_int, c_int]),
+    "lsdsort_u64_device": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_size, c_size, c_int, ctypes.c_void_p]),
+    "lsdsort_records_device": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, ctypes.c_void_p, c_size, c_size, c_int,
+                                       ctypes.c_void_p]),
+    "lsdsort_wide_check_device": (c_int, [ctypes.c_void_p, c_size, c_int, c_int, c_int, ctypes.c_void_p]),
     "lsdsort_check_device": (c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "lsdsort_u32_device_timed": (c_int, [c_u32p, c_u32p, ctypes.c_void_p, c_size, c_size, c_int, c_int,
                                          ctypes.c_void_p, ctypes.POINTER(LsdsortTiming)]),

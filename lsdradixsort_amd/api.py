@@ -19,7 +19,7 @@ from .errors import LSDSORT_ALGO_ONESWEEP, LSDSORT_ALGO_STAGED, check
 __all__ = [
     "sort", "sort_pairs", "to_device", "to_host", "workspace_bytes", "GPULSDRadixSort",
     "GPULSDRadixSortTimed", "BuildHistograms", "BuildOffsets", "RankScatter", "DigitHistograms",
-    "MSBPartition", "SplitterPartition", "GPUSortTyped", "tile_keys", "set_tile_config", "set_rank_method", "rank_method", "set_xcd_chunk", "LSDSORT_ALGO_ONESWEEP", "LSDSORT_ALGO_STAGED",
+    "MSBPartition", "SplitterPartition", "GPUSortTyped", "GPUSortWide", "tile_keys", "set_tile_config", "set_rank_method", "rank_method", "set_xcd_chunk", "LSDSORT_ALGO_ONESWEEP", "LSDSORT_ALGO_STAGED",
 ]
 
 
@@ -178,6 +178,46 @@ def GPUSortTyped(d_keys, key_type: str = "int32", descending: bool = False, d_va
     if check_fault and n:
         check(lib().lsdsort_check_device(workspace.data_ptr(), _stream(stream)), "lsdsort_check_device")
     return d_keys if not pairs else (d_keys, d_vals)
+
+
+def GPUSortWide(d_keys, d_vals=None, r: int = 8, workspace=None, stream=None, check_fault: bool = False):
+    """64-bit keys and / or 64-bit payloads, in place (``lsdsort_u64_device`` / ``lsdsort_records_device``).
+    ``d_keys``: int64 CUDA tensor (uint64 bit patterns) or int32 (uint32 bit patterns); ``d_vals``: None (64-bit keys
+    only), int32 or int64.  The 32/32 combination is ``GPULSDRadixSort``.  Stable by key."""
+    torch = _torch()
+    bits = {torch.int32: 32, torch.int64: 64}
+    if not (isinstance(d_keys, torch.Tensor) and d_keys.is_cuda and d_keys.is_contiguous() and d_keys.dtype in bits):
+        raise TypeError("d_keys: a contiguous int32 or int64 CUDA tensor")
+    kb = bits[d_keys.dtype]
+    vb = 0
+    if d_vals is not None:
+        if not (isinstance(d_vals, torch.Tensor) and d_vals.is_cuda and d_vals.is_contiguous() and d_vals.dtype in bits):
+            raise TypeError("d_vals: a contiguous int32 or int64 CUDA tensor")
+        if d_vals.numel() != d_keys.numel():
+            raise ValueError("keys and vals differ in length")
+        vb = bits[d_vals.dtype]
+    if (kb, vb) in ((32, 0), (32, 32)):
+        raise ValueError("32-bit keys with no or 32-bit payloads: use GPULSDRadixSort")
+    n = d_keys.numel()
+    need = int(lib().lsdsort_wide_workspace_bytes(n, r, kb, vb))
+    if need == 0:
+        raise errors.LsdsortError(errors.LSDSORT_ERR_INVALID_ARG, "lsdsort_wide_workspace_bytes", "bad (n, radix_bits)")
+    if workspace is None:
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                workspace = torch.empty(need, dtype=torch.uint8, device=d_keys.device)
+        else:
+            workspace = torch.empty(need, dtype=torch.uint8, device=d_keys.device)
+    if vb == 0:
+        st = lib().lsdsort_u64_device(d_keys.data_ptr(), workspace.data_ptr(), workspace.numel(), n, r, _stream(stream))
+        check(st, "lsdsort_u64_device")
+    else:
+        st = lib().lsdsort_records_device(d_keys.data_ptr(), d_vals.data_ptr(), kb, vb, workspace.data_ptr(), workspace.numel(), n, r,
+                                          _stream(stream))
+        check(st, "lsdsort_records_device")
+    if check_fault and n:
+        check(lib().lsdsort_wide_check_device(workspace.data_ptr(), n, r, kb, vb, _stream(stream)), "lsdsort_wide_check_device")
+    return d_keys if d_vals is None else (d_keys, d_vals)
 
 
 def GPULSDRadixSortTimed(d_keys, r: int = 8, d_vals=None, algorithm: int = LSDSORT_ALGO_ONESWEEP, workspace=None,

@@ -246,8 +246,12 @@ constexpr int joint_copies(int radix_bits, bool wide, int counters_per_table)
 template <int R, int THREADS, bool WIDE = false>
 __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                   uint32_t region0_keys, uint32_t* __restrict__ joint,
-                                                                  uint32_t vec_chunks, const KeyTransform xf)
+                                                                  uint32_t vec_chunks, const KeyTransform xf,
+                                                                  uint32_t first_key)
 {
+    // `keys` may be a slice [first_key, first_key + n) of the array being sorted (the host entry counts each chunk as
+    // it arrives over PCIe): pass-0 regions are by position in the WHOLE array; first_key is a multiple of the chunk.
+    const uint32_t chunk_base = first_key / (uint32_t)(THREADS * 4);
     static_assert(!WIDE || R == 4, "wide fields are laid out for 4-bit digits with 4 region bits");
     constexpr int P = 32 / R;
     constexpr int B = region_bits_for_radix(R);
@@ -407,7 +411,7 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
         for (int u = 0; u < VPT; u++) {
             if (c + u < vec_chunks) {
                 // region0_keys is a multiple of the chunk (THREADS*4 keys), so the chunk is in one region
-                const uint32_t region0 = ((c + u) * (uint32_t)(THREADS * 4)) / region0_keys;
+                const uint32_t region0 = ((chunk_base + c + u) * (uint32_t)(THREADS * 4)) / region0_keys;
                 if (looks_uniform(cur[u].x)) {
                     count_vec_checked(cur[u], region0);
                 } else {
@@ -427,7 +431,7 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
         // a step's keys are consecutive, so a wave stays inside one pass-0 region except at a boundary
         const uint32_t tail_begin = vec_chunks * (THREADS * 4);
         for (size_t i = (size_t)tail_begin + (size_t)blockIdx.x * THREADS + tid; i < n; i += (size_t)gridDim.x * THREADS)
-            count_key_checked(xf.on ? to_sortable(keys[i], xf) : keys[i], (uint32_t)(i / region0_keys));
+            count_key_checked(xf.on ? to_sortable(keys[i], xf) : keys[i], (uint32_t)((first_key + i) / region0_keys));
     }
     __syncthreads();
     // Flush.  Pass 0's fields sit region-major in LDS: all 64 lanes of a wave share their position
@@ -469,7 +473,7 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
 
 template <int R, int THREADS, bool WIDE = false>
 static hipError_t launch_joint_inst(const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* joint,
-                                    hipStream_t stream, const KeyTransform& xf)
+                                    hipStream_t stream, const KeyTransform& xf, uint32_t first_key)
 {
     constexpr int P = 32 / R;
     constexpr int F = (1 << R) << region_bits_for_radix(R);
@@ -483,27 +487,27 @@ static hipError_t launch_joint_inst(const uint32_t* keys, uint32_t n, uint32_t r
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (attr != hipSuccess) return attr;
     }
-    if (region0_keys == 0 || region0_keys % (THREADS * 4) != 0) return hipErrorInvalidValue;
+    if (region0_keys == 0 || region0_keys % (THREADS * 4) != 0 || first_key % (THREADS * 4) != 0) return hipErrorInvalidValue;
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const uint32_t vec_chunks = aligned ? n / (THREADS * 4) : 0;
     uint32_t blocks = aligned ? (vec_chunks + kHistVecPerThread - 1) / kHistVecPerThread : (n + THREADS * 16 - 1) / (THREADS * 16);
     const uint32_t cap = (uint32_t)(2048 * 256 / THREADS);   // enough waves to cover HBM latency
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds_bytes, stream, keys, n, region0_keys, joint, vec_chunks, xf);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds_bytes, stream, keys, n, region0_keys, joint, vec_chunks, xf, first_key);
     return hipGetLastError();
 }
 
 hipError_t launch_joint_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys,
-                                   uint32_t* joint, hipStream_t stream, const KeyTransform& xf)
+                                   uint32_t* joint, hipStream_t stream, const KeyTransform& xf, uint32_t first_key)
 {
     switch (radix_bits) {
 #ifdef LSD_R4_NARROW_HIST
-        case 4: return launch_joint_inst<4, 256>(keys, n, region0_keys, joint, stream, xf);
+        case 4: return launch_joint_inst<4, 256>(keys, n, region0_keys, joint, stream, xf, first_key);
 #else
-        case 4: return launch_joint_inst<4, LSD_R4_HIST_THREADS, true>(keys, n, region0_keys, joint, stream, xf);   // 64 KiB of counters per workgroup
+        case 4: return launch_joint_inst<4, LSD_R4_HIST_THREADS, true>(keys, n, region0_keys, joint, stream, xf, first_key);   // 64 KiB of counters per workgroup
 #endif
-        case 8: return launch_joint_inst<8, (LSD_R8_REGION_BITS == 3 ? LSD_R8_HIST_THREADS3 : LSD_R8_HIST_THREADS)>(keys, n, region0_keys, joint, stream, xf);   // 32 / 64 / 128 KiB of counters per workgroup at 3 / 4 / 5 bits
+        case 8: return launch_joint_inst<8, (LSD_R8_REGION_BITS == 3 ? LSD_R8_HIST_THREADS3 : LSD_R8_HIST_THREADS)>(keys, n, region0_keys, joint, stream, xf, first_key);   // 32 / 64 / 128 KiB of counters per workgroup at 3 / 4 / 5 bits
         default: return hipErrorInvalidValue;
     }
 }

@@ -142,8 +142,10 @@ hipError_t launch_scan_digit_counts(int radix_bits, int groups, const uint32_t* 
 // Stage 1, onesweep with regions (radix 4 and 8): joint[p][(digit_p << B) | region_p(key)], B =
 // region_bits_for_radix, for every pass in one read; `region0_keys` is R0 (pass-0 regions are by
 // position).  joint must be zero on entry.
+// `keys` may be the slice [first_key, first_key + n) of the array (first_key a multiple of 4096): counts accumulate.
 hipError_t launch_joint_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys,
-                                   uint32_t* joint, hipStream_t stream, const KeyTransform& xform = KeyTransform{});
+                                   uint32_t* joint, hipStream_t stream, const KeyTransform& xform = KeyTransform{},
+                                   uint32_t first_key = 0);
 
 // Stage 2, onesweep: region tables of every pass from the joint counts (`regions` = 16 or 32) or
 // from plain digit histograms (`regions` = 1; passes may then be 1 for the multi-GPU partition).

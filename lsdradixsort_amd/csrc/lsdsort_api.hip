@@ -13,6 +13,7 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -275,13 +276,33 @@ struct StageEvents {
         if (s__ != LSDSORT_OK) return s__; \
     } while (0)
 
+// Host-pointer entry (lsdsort_u32 and friends): the input arrives over PCIe in chunks on a copy stream and each
+// chunk's share of the upfront histogram runs behind it on the sort's stream, so stage 1 is hidden under the
+// transfer (the passes need every key and cannot start earlier; the copy back needs the last pass).
+struct HostFeed {
+    const uint32_t* host_keys = nullptr;
+    const uint32_t* host_vals = nullptr;
+    hipStream_t copy = nullptr;
+    hipEvent_t* events = nullptr;   // one per chunk, plus one for the payloads
+};
+#ifndef LSD_FEED_CHUNK_LOG2
+#define LSD_FEED_CHUNK_LOG2 24
+#endif
+const size_t kFeedChunkKeys = [] {                                      // 64 MiB per chunk
+    const char* e = getenv("LSDSORT_FEED_CHUNK_LOG2");                  // experiment knob (tools/host_entry_perf.py)
+    const int v = e ? atoi(e) : LSD_FEED_CHUNK_LOG2;
+    return (size_t)1 << (v >= 22 && v <= 30 ? v : LSD_FEED_CHUNK_LOG2);
+}();
+constexpr int kMaxFeedEvents = (int)(((size_t)LSDSORT_MAX_KEYS >> 22) + 3);
+
 // The pass loop.  Marks (when timing), onesweep: 0 start | 1 after clear | 2 after stage 1 |
 // 3 after stage 2 | 4 after the last pass.  Staged: 0 start | 1 after clear | 2, 3 (empty) | then per
 // pass three marks: after its histogram, after its offset scan, after its scatter.
 int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, size_t n, int radix_bits,
              int algorithm, hipStream_t stream, StageEvents* ev, lsdsort_timing* timing,
-             const lsd::KeyTransform& xf = lsd::KeyTransform{})
+             const lsd::KeyTransform& xf = lsd::KeyTransform{}, const HostFeed* feed = nullptr)
 {
+    if (feed && algorithm != LSDSORT_ALGO_ONESWEEP) return LSDSORT_ERR_INVALID_ARG;
     if (xf.on && (algorithm != LSDSORT_ALGO_ONESWEEP || radix_bits < 4)) return LSDSORT_ERR_UNSUPPORTED;
     if (!valid_radix(radix_bits)) return LSDSORT_ERR_INVALID_ARG;
     if (algorithm != LSDSORT_ALGO_ONESWEEP && algorithm != LSDSORT_ALGO_STAGED) return LSDSORT_ERR_INVALID_ARG;
@@ -317,10 +338,31 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     if (algorithm == LSDSORT_ALGO_ONESWEEP) {
         uint32_t* counts = reinterpret_cast<uint32_t*>(ws + L.counts);
         tables = reinterpret_cast<uint32_t*>(ws + L.tables);
-        if (L.regions > 1)
-            LSD_HIP(lsd::launch_joint_histograms(radix_bits, d_keys, (uint32_t)n, L.region0, counts, stream, xf));
-        else
-            LSD_HIP(lsd::launch_digit_histograms(radix_bits, passes, 0, d_keys, (uint32_t)n, counts, stream));
+        // stage 1 over [first, first + len): the whole array at once, or chunk by chunk behind the host's copies
+        auto histogram = [&](size_t first, size_t len) -> int {
+            if (L.regions > 1)
+                LSD_HIP(lsd::launch_joint_histograms(radix_bits, d_keys + first, (uint32_t)len, L.region0, counts, stream, xf, (uint32_t)first));
+            else
+                LSD_HIP(lsd::launch_digit_histograms(radix_bits, passes, 0, d_keys + first, (uint32_t)len, counts, stream));
+            return LSDSORT_OK;
+        };
+        if (!feed) {
+            LSD_TRY(histogram(0, n));
+        } else {
+            int e = 0;
+            for (size_t first = 0; first < n; first += kFeedChunkKeys, e++) {
+                const size_t len = n - first < kFeedChunkKeys ? n - first : kFeedChunkKeys;
+                LSD_HIP(hipMemcpyAsync(d_keys + first, feed->host_keys + first, len * sizeof(uint32_t), hipMemcpyHostToDevice, feed->copy));   // .cu:1001
+                LSD_HIP(hipEventRecord(feed->events[e], feed->copy));
+                LSD_HIP(hipStreamWaitEvent(stream, feed->events[e], 0));
+                LSD_TRY(histogram(first, len));
+            }
+            if (pairs) {
+                LSD_HIP(hipMemcpyAsync(d_vals, feed->host_vals, n * sizeof(uint32_t), hipMemcpyHostToDevice, feed->copy));
+                LSD_HIP(hipEventRecord(feed->events[e], feed->copy));
+                LSD_HIP(hipStreamWaitEvent(stream, feed->events[e], 0));
+            }
+        }
         if (ev) LSD_TRY(ev->mark());
         LSD_HIP(lsd::launch_scan_regions(radix_bits, passes, L.regions, counts, (uint32_t)n, (uint32_t)shape->tile(),
                                          L.region0, tables, stream));
@@ -400,37 +442,73 @@ int read_fault(void* d_ws, hipStream_t stream)
     return fault ? LSDSORT_ERR_DEVICE_FAULT : LSDSORT_OK;
 }
 
+// Device buffers, streams and events of the host-pointer entries, kept per device between calls (the reference
+// allocates and frees around every sort, .cu:967-975 / .cu:1020-1028; a hipMalloc + hipFree pair of this size costs
+// milliseconds).  Calls on one device take turns (the mutex); lsdsort_release_host_cache() gives the memory back.
+struct HostCache {
+    std::mutex mutex;
+    uint32_t* d_keys = nullptr;
+    uint32_t* d_vals = nullptr;
+    void* d_ws = nullptr;
+    size_t keys_bytes = 0, vals_bytes = 0, ws_bytes = 0;
+    hipStream_t copy = nullptr, compute = nullptr;
+    hipEvent_t events[kMaxFeedEvents] = {};
+    bool ready = false;
+};
+HostCache g_host_cache[64];
+
+int grow(void** ptr, size_t* have, size_t need)
+{
+    if (*have >= need) return LSDSORT_OK;
+    if (*ptr) {
+        (void)hipFree(*ptr);
+        *ptr = nullptr;
+        *have = 0;
+    }
+    LSD_HIP(hipMalloc(ptr, need));
+    *have = need;
+    return LSDSORT_OK;
+}
+
 int sort_host(uint32_t* keys, uint32_t* vals, size_t n, int radix_bits)
 {
     if (!valid_radix(radix_bits)) return LSDSORT_ERR_INVALID_ARG;
     if (n > LSDSORT_MAX_KEYS) return LSDSORT_ERR_TOO_LARGE;
     if (n == 0) return LSDSORT_OK;
     if (!keys) return LSDSORT_ERR_INVALID_ARG;
-    LSD_TRY(check_device_ready());
+    int dev = 0;
+    LSD_TRY(check_device_ready(&dev));
     const bool pairs = vals != nullptr;
     const size_t ws_bytes = lsdsort_workspace_bytes_ex(n, radix_bits, pairs ? 1 : 0, LSDSORT_ALGO_ONESWEEP);
     const size_t bytes = n * sizeof(uint32_t);
-    uint32_t *d_keys = nullptr, *d_vals = nullptr;
-    void* d_ws = nullptr;
-    int status = LSDSORT_OK;
-    auto body = [&]() -> int {
-        LSD_HIP(hipMalloc(&d_keys, bytes));
-        if (pairs) LSD_HIP(hipMalloc(&d_vals, bytes));
-        LSD_HIP(hipMalloc(&d_ws, ws_bytes));
-        LSD_HIP(hipMemcpy(d_keys, keys, bytes, hipMemcpyHostToDevice));                  // .cu:1001
-        if (pairs) LSD_HIP(hipMemcpy(d_vals, vals, bytes, hipMemcpyHostToDevice));
-        LSD_TRY(run_sort(d_keys, d_vals, d_ws, ws_bytes, n, radix_bits, LSDSORT_ALGO_ONESWEEP, nullptr, nullptr,
-                         nullptr));                                                     // .cu:1003
-        LSD_TRY(read_fault(d_ws, nullptr));
-        LSD_HIP(hipMemcpy(keys, d_keys, bytes, hipMemcpyDeviceToHost));                  // .cu:1005
-        if (pairs) LSD_HIP(hipMemcpy(vals, d_vals, bytes, hipMemcpyDeviceToHost));
-        return LSDSORT_OK;
-    };
-    status = body();
-    if (d_ws) (void)hipFree(d_ws);
-    if (d_vals) (void)hipFree(d_vals);
-    if (d_keys) (void)hipFree(d_keys);
-    return status;
+    HostCache& C = g_host_cache[dev];
+    std::lock_guard<std::mutex> lock(C.mutex);
+    if (!C.ready) {
+        LSD_HIP(hipStreamCreateWithFlags(&C.copy, hipStreamNonBlocking));
+        LSD_HIP(hipStreamCreateWithFlags(&C.compute, hipStreamNonBlocking));
+        for (int i = 0; i < kMaxFeedEvents; i++) LSD_HIP(hipEventCreateWithFlags(&C.events[i], hipEventDisableTiming));
+        C.ready = true;
+    }
+    LSD_TRY(grow(reinterpret_cast<void**>(&C.d_keys), &C.keys_bytes, bytes));
+    if (pairs) LSD_TRY(grow(reinterpret_cast<void**>(&C.d_vals), &C.vals_bytes, bytes));
+    LSD_TRY(grow(&C.d_ws, &C.ws_bytes, ws_bytes));
+    HostFeed feed;
+    feed.host_keys = keys;
+    feed.host_vals = vals;
+    feed.copy = C.copy;
+    feed.events = C.events;
+    // H2D in chunks with stage 1 behind each (.cu:1001), the passes (.cu:1003), the copy back (.cu:1005)
+    const int status = run_sort(C.d_keys, pairs ? C.d_vals : nullptr, C.d_ws, C.ws_bytes, n, radix_bits, LSDSORT_ALGO_ONESWEEP, C.compute,
+                                nullptr, nullptr, lsd::KeyTransform{}, &feed);
+    if (status != LSDSORT_OK) {
+        (void)hipStreamSynchronize(C.copy);       // nothing of the caller's array may still be in flight when we return
+        (void)hipStreamSynchronize(C.compute);
+        return status;
+    }
+    LSD_TRY(read_fault(C.d_ws, C.compute));       // synchronises the sort
+    LSD_HIP(hipMemcpy(keys, C.d_keys, bytes, hipMemcpyDeviceToHost));
+    if (pairs) LSD_HIP(hipMemcpy(vals, C.d_vals, bytes, hipMemcpyDeviceToHost));
+    return LSDSORT_OK;
 }
 
 struct MsbLayout {
@@ -547,6 +625,25 @@ LSDSORT_API int lsdsort_debug_set_stats(unsigned long long* d_stats)
     return LSDSORT_OK;
 }
 #endif
+
+int lsdsort_release_host_cache(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        (void)hipGetLastError();
+        return LSDSORT_ERR_NO_DEVICE;
+    }
+    HostCache& C = g_host_cache[dev];
+    std::lock_guard<std::mutex> lock(C.mutex);
+    if (C.d_keys) (void)hipFree(C.d_keys);
+    if (C.d_vals) (void)hipFree(C.d_vals);
+    if (C.d_ws) (void)hipFree(C.d_ws);
+    C.d_keys = C.d_vals = nullptr;
+    C.d_ws = nullptr;
+    C.keys_bytes = C.vals_bytes = C.ws_bytes = 0;
+    (void)hipGetLastError();
+    return LSDSORT_OK;
+}
 
 int lsdsort_prepare_device(void)
 {

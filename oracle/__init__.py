@@ -54,6 +54,9 @@ def lib() -> ctypes.CDLL:
         if not os.path.exists(_LIB_PATH):
             build(with_ref=False)
         L = _load(_LIB_PATH)
+        if not hasattr(L, "oracle_std_sort_u64"):       # a library built before the 64-bit legs were added
+            build(with_ref=False)
+            L = _load(_LIB_PATH)
         sz = ctypes.c_size_t
         L.oracle_get_r_bits.restype = ctypes.c_uint32
         L.oracle_get_r_bits.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_int]
@@ -74,6 +77,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_first_mismatch.argtypes = [_u32p, _u32p, sz]
         L.oracle_std_sort.argtypes = [_u32p, sz]
         L.oracle_std_stable_sort_pairs.argtypes = [_u32p, _u32p, sz]
+        L.oracle_std_sort_u64.argtypes = [_u64p, sz]
+        L.oracle_std_stable_sort_records.argtypes = [_u64p, _u64p, sz]
         L.oracle_fill_mt19937.argtypes = [_u32p, sz, ctypes.c_uint32]
         L.oracle_time_std_sort.restype = ctypes.c_double
         L.oracle_time_std_sort.argtypes = [_u32p, sz]
@@ -138,6 +143,21 @@ def std_sort(keys) -> np.ndarray:
 def std_stable_sort_pairs(keys, vals):
     k, v = _u32(keys).copy(), _u32(vals).copy()
     lib().oracle_std_stable_sort_pairs(_p(k), _p(v), k.size)
+    return k, v
+
+
+def std_sort_u64(keys) -> np.ndarray:
+    """std::sort on uint64 keys (no reference counterpart: the reference is uint32 only, .cu:62)."""
+    out = np.ascontiguousarray(keys, dtype=np.uint64).copy()
+    lib().oracle_std_sort_u64(_p64(out), out.size)
+    return out
+
+
+def std_stable_sort_records(keys, vals):
+    """std::stable_sort by key over (key, payload) records; both widened to uint64."""
+    k = np.ascontiguousarray(keys, dtype=np.uint64).copy()
+    v = np.ascontiguousarray(vals, dtype=np.uint64).copy()
+    lib().oracle_std_stable_sort_records(_p64(k), _p64(v), k.size)
     return k, v
 
 

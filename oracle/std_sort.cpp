@@ -54,6 +54,22 @@ ORACLE_API void oracle_std_stable_sort_pairs(uint32_t* keys, uint32_t* vals, siz
     }
 }
 
+// 64-bit keys / payloads (no reference counterpart, .cu:62 is uint32 only): the unique answers are std::sort on
+// uint64 and std::stable_sort by key over (key, payload) records.  `vals` may be null (keys only).
+ORACLE_API void oracle_std_sort_u64(uint64_t* keys, size_t count)
+{
+    std::sort(keys, keys + count);
+}
+
+ORACLE_API void oracle_std_stable_sort_records(uint64_t* keys, uint64_t* vals, size_t count)
+{
+    std::vector<size_t> idx(count);
+    std::iota(idx.begin(), idx.end(), (size_t)0);
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return keys[a] < keys[b]; });
+    std::vector<uint64_t> k(keys, keys + count), v(vals, vals + count);
+    for (size_t i = 0; i < count; i++) { keys[i] = k[idx[i]]; vals[i] = v[idx[i]]; }
+}
+
 ORACLE_API void oracle_fill_mt19937(uint32_t* out, size_t count, uint32_t seed)
 {
     std::mt19937 gen(seed);

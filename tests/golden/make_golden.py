@@ -96,6 +96,21 @@ def main():
     out["pairs_keys"], out["pairs_vals"] = pk, pv
     out["pairs_sorted_keys"], out["pairs_sorted_vals"] = ek, ev
 
+    # 64-bit keys and payloads (the reference is uint32 only, .cu:62): std::sort / std::stable_sort.
+    lo, hi = oracle.mt19937_keys(9001, 21).astype(np.uint64), oracle.mt19937_keys(9001, 22).astype(np.uint64)
+    k64 = (hi << np.uint64(32)) | lo
+    k64[::7] = (k64[::7] & np.uint64(0xFFFFFFFF)) | np.uint64(5 << 32)              # many equal high words
+    k64[1::11] = np.uint64(0xFFFFFFFFFFFFFFFF)                                      # collides with tail padding in both words
+    k64[2::13] = k64[0]                                                             # exact duplicates
+    out["u64_keys"] = k64
+    out["u64_sorted"] = oracle.std_sort_u64(k64)
+    v64 = (np.arange(9001, dtype=np.uint64) << np.uint64(33)) | np.uint64(1)
+    rk, rv = oracle.std_stable_sort_records(k64, v64)
+    out["u64_vals"], out["u64_records_keys"], out["u64_records_vals"] = v64, rk, rv
+    k32 = (oracle.mt19937_keys(9001, 23) % 257).astype(np.uint32)
+    rk32, rv32 = oracle.std_stable_sort_records(k32, v64)
+    out["u32v64_keys"], out["u32v64_sorted_keys"], out["u32v64_sorted_vals"] = k32, rk32.astype(np.uint32), rv32
+
     # mt19937 known-answer: the 10000th output of default-seeded std::mt19937 (C++ standard).
     out["mt19937_kat"] = np.array([5489, 9999, 4123659995], dtype=np.uint64)
 

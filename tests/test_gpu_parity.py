@@ -78,6 +78,31 @@ def test_host_pointer_sort(gpu, golden, oracle_mod):
     assert gpu.sort(empty).size == 0
 
 
+def test_host_pointer_sort_spans_chunks(gpu, oracle_mod):
+    """The host entry feeds the device in 64 MiB chunks (stage 1 runs behind each): a ragged size spanning three chunks,
+    keys and pairs, against std::sort / std::stable_sort, twice (the second call reuses the cached device buffers),
+    then a smaller and a larger call on the same cache."""
+    n = 2 * (1 << 24) + (1 << 22) + 4097 + 3
+    keys = oracle_mod.mt19937_keys(n, 77)
+    expect = oracle_mod.std_sort(keys)
+    for _ in range(2):
+        got = keys.copy()
+        gpu.sort(got)
+        assert np.array_equal(got, expect)
+    for r in (4, 2):
+        small = keys[: (1 << 20) + 5].copy()
+        assert np.array_equal(gpu.sort(small, radix_bits=r), np.sort(keys[: (1 << 20) + 5])), r
+    dup = (keys % 100003).astype(np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    ek, ev = oracle_mod.std_stable_sort_pairs(dup, vals)
+    k, v = dup.copy(), vals.copy()
+    gpu.sort_pairs(k, v)
+    assert np.array_equal(k, ek) and np.array_equal(v, ev)
+    assert gpu.lib().lsdsort_release_host_cache() == 0
+    got = keys[:12345].copy()
+    assert np.array_equal(gpu.sort(got), np.sort(keys[:12345]))          # after a release the cache is rebuilt
+
+
 def test_host_pointer_pairs(gpu, golden):
     k, v = golden["pairs_keys"].copy(), golden["pairs_vals"].copy()
     gpu.sort_pairs(k, v)
@@ -590,6 +615,74 @@ def test_typed_pairs_are_stable(gpu, oracle_mod, key_type, descending):
     assert np.array_equal(vals.cpu().numpy(), order.astype(np.int32))
     got = t.cpu().numpy() if key_type != "uint32" else gpu.to_host(t)
     assert np.array_equal(got, host[order])
+
+
+# ----------------------------------------------------------------------------- 64-bit keys and payloads
+def _i64(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64)).cuda()
+
+
+def _u64(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("r", [8, 4])
+def test_u64_golden(gpu, golden, r):
+    """uint64 keys, and records with 64-bit payloads, against the committed std::sort / std::stable_sort vectors: equal
+    high words, exact duplicates, all-ones keys (the tail padding's value in BOTH words)."""
+    d = _i64(golden["u64_keys"])
+    gpu.GPUSortWide(d, r=r, check_fault=True)
+    assert np.array_equal(_u64(d), golden["u64_sorted"])
+    dk, dv = _i64(golden["u64_keys"]), _i64(golden["u64_vals"])
+    gpu.GPUSortWide(dk, dv, r=r, check_fault=True)
+    assert np.array_equal(_u64(dk), golden["u64_records_keys"]) and np.array_equal(_u64(dv), golden["u64_records_vals"])
+    k32, v64 = gpu.to_device(golden["u32v64_keys"]), _i64(golden["u64_vals"])
+    gpu.GPUSortWide(k32, v64, r=r, check_fault=True)
+    assert np.array_equal(gpu.to_host(k32), golden["u32v64_sorted_keys"]) and np.array_equal(_u64(v64), golden["u32v64_sorted_vals"])
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 4097, (1 << 20) + 5, (1 << 22) + 12345])
+def test_u64_keys_vs_oracle(gpu, oracle_mod, n):
+    rng = np.random.default_rng(n + 3)
+    shapes = {
+        "uniform": rng.integers(0, 1 << 64, size=n, dtype=np.uint64),
+        "low_word_only": rng.integers(0, 1 << 32, size=n, dtype=np.uint64),
+        "high_word_only": rng.integers(0, 1 << 32, size=n, dtype=np.uint64) << np.uint64(32),
+        "all_ones": np.full(n, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64),
+        "few_values": rng.integers(0, 5, size=n, dtype=np.uint64) * np.uint64(0x0101010101010101),
+    }
+    for name, keys in shapes.items():
+        d = _i64(keys)
+        gpu.GPUSortWide(d, check_fault=True)
+        assert np.array_equal(_u64(d), oracle_mod.std_sort_u64(keys)), (name, n)
+
+
+@pytest.mark.parametrize("kb,vb", [(64, 64), (64, 32), (32, 64)])
+def test_wide_records_are_stable(gpu, oracle_mod, kb, vb):
+    """Records = key + payload: equal keys keep their input order (payload = input index), ragged size."""
+    import torch
+
+    n = (1 << 21) + 777
+    rng = np.random.default_rng(kb + vb)
+    if kb == 64:
+        keys = (rng.integers(0, 50, size=n, dtype=np.uint64) << np.uint64(32)) | rng.integers(0, 40, size=n, dtype=np.uint64)
+        dk = _i64(keys)
+    else:
+        keys = rng.integers(0, 1000, size=n, dtype=np.uint64)
+        dk = gpu.to_device(keys.astype(np.uint32))
+    vals = np.arange(n, dtype=np.uint64)
+    dv = _i64(vals) if vb == 64 else gpu.to_device(vals.astype(np.uint32))
+    gpu.GPUSortWide(dk, dv, check_fault=True)
+    ek, ev = oracle_mod.std_stable_sort_records(keys, vals)
+    got_k = _u64(dk) if kb == 64 else gpu.to_host(dk).astype(np.uint64)
+    got_v = _u64(dv) if vb == 64 else gpu.to_host(dv).astype(np.uint64)
+    assert np.array_equal(got_k, ek) and np.array_equal(got_v, ev)
+    with pytest.raises(ValueError):
+        gpu.GPUSortWide(gpu.to_device(np.zeros(4, dtype=np.uint32)))              # 32/0 is the ordinary entry
+    assert gpu.lib().lsdsort_wide_workspace_bytes(100, 8, 32, 32) == 0
+    assert gpu.lib().lsdsort_u64_device(dk.data_ptr(), None, 0, 10, 8, None) == -4   # LSDSORT_ERR_WORKSPACE
 
 
 def test_typed_sort_limits(gpu):

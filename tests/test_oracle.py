@@ -146,3 +146,15 @@ def test_golden_regenerates_identically(oracle_mod, golden):
     assert np.array_equal(oracle_mod.ref_lsd_sort(keys, 8), golden["sorted__uniform_16384_seed0"])
     assert np.array_equal(oracle_mod.ref_build_histograms(golden["hist_in"], 1024, 8, 1), golden["hist_block1024_r8_bg1"])
     assert np.array_equal(oracle_mod.ref_prefix_sum(golden["scan_in"]), golden["scan_out"])
+
+
+def test_u64_legs_against_golden_and_numpy(oracle_mod, golden):
+    """The 64-bit legs of the oracle (std::sort on uint64, std::stable_sort over records; SURVEY 8f.4 -- the reference is
+    uint32 only, .cu:62, so these are pinned by the committed vectors and by numpy's own stable sort)."""
+    k = golden["u64_keys"]
+    assert np.array_equal(oracle_mod.std_sort_u64(k), golden["u64_sorted"])
+    assert np.array_equal(golden["u64_sorted"], np.sort(k))
+    rk, rv = oracle_mod.std_stable_sort_records(k, golden["u64_vals"])
+    order = np.argsort(k, kind="stable")
+    assert np.array_equal(rk, k[order]) and np.array_equal(rv, golden["u64_vals"][order])
+    assert np.array_equal(rk, golden["u64_records_keys"]) and np.array_equal(rv, golden["u64_records_vals"])
