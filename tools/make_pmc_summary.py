@@ -10,8 +10,8 @@ the upfront histogram kernel reads every key exactly once (4*n bytes) and writes
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {}
-for tag, key, n, pairs in (("r1_keys_r8", "rank_scatter_r8", 1 << 28, False), ("r1_keys_r4", "rank_scatter_r4", 1 << 28, False),
-                           ("r1_pairs_r8", "rank_scatter_r8_pairs", 1 << 27, True)):
+for tag, key, n, pairs in (("r2_keys_r8", "rank_scatter_r8", 1 << 28, False), ("r2_keys_r4", "rank_scatter_r4", 1 << 28, False),
+                           ("r2_pairs_r8", "rank_scatter_r8_pairs", 1 << 27, True)):
     path = os.path.join(ROOT, "profiles", tag, "summary.json")
     if not os.path.exists(path):
         continue
