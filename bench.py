@@ -75,6 +75,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=26)
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configs reported under 'extra'")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic in this very run (N = 1 only; "
+                         "the committed profiles/pmc_summary.json figure is reported instead, labelled as such)")
     args = ap.parse_args(argv)
     if args.gpus not in (1, 2, 4, 8):
         ap.error("--gpus must be 1, 2, 4 or 8 (MSB buckets: one rank per power-of-two share of the key space)")
@@ -151,6 +154,61 @@ def spawn_ranks(n_ranks, argv, device_count=None, child_cmd=None, timeout=None, 
     else:
         sys.stderr.write(text)
     return rc
+
+
+def live_pmc_traffic(radix_bits, pairs, log2n, timeout=240):
+    """HBM bytes per launch of the rank-and-scatter kernel measured NOW, as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE and
+    WRITE_SIZE from SEPARATE `rocprofv3 --pmc` passes (counters only, no tracing), each over a child process that runs the same sort
+    on the same input (tools/prof_target.py; the program after `--` is python3 itself); both counters are in KiB; FETCH_SIZE reports
+    half of a coalesced streaming read and is doubled, the doubling calibrated on the upfront histogram kernel's known 4*n read.
+    Returns None (with a reason on stderr) if rocprofv3 is missing or a pass fails: the caller then falls back to the committed figure."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        print("bench.py: rocprofv3 not found; roofline.traffic falls back to profiles/pmc_summary.json", file=sys.stderr)
+        return None
+    n = 1 << log2n
+    out = tempfile.mkdtemp(prefix="lsd_pmc_", dir="/tmp")
+    target = [sys.executable, os.path.join(ROOT, "tools", "prof_target.py"), "--log2-keys", str(log2n), "--radix-bits", str(radix_bits),
+              "--steps", "2"] + (["--pairs"] if pairs else [])
+    env = dict(os.environ, TMPDIR="/tmp")
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, counter)
+            p = subprocess.run(["rocprofv3", "--pmc", counter, "-d", d, "--output-format", "csv", "--"] + target, cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                print(f"bench.py: rocprofv3 --pmc {counter} failed (rc {p.returncode}); roofline.traffic falls back", file=sys.stderr)
+                return None
+            scatter, hist, dur = [], [], []
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != counter:
+                    continue
+                if "rank_scatter_kernel" in row["Kernel_Name"]:
+                    scatter.append(float(row["Counter_Value"]))
+                    dur.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+                elif "histograms_kernel" in row["Kernel_Name"]:
+                    hist.append(float(row["Counter_Value"]))
+            if not scatter:
+                return None
+            got[counter] = (sum(scatter) / len(scatter) * 1024.0, (sum(hist) / len(hist) * 1024.0) if hist else None,
+                            sum(dur) / len(dur) / 1e3, len(scatter))
+    except Exception as e:      # a profiler problem must not take the benchmark down
+        print(f"bench.py: live PMC pass failed ({e}); roofline.traffic falls back", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    fetch, hist_fetch, fetch_us, launches = got["FETCH_SIZE"]
+    write, _, write_us, _ = got["WRITE_SIZE"]
+    return {"bytes": int(2.0 * fetch + write), "fetch_bytes_corrected": int(2.0 * fetch), "write_bytes": int(write),
+            "calibration_ratio": round(2.0 * hist_fetch / (4.0 * n), 4) if hist_fetch else None, "launches": launches,
+            "kernel_us_under_profiler": round((fetch_us + write_us) / 2.0, 1)}
 
 
 def timed_steps(run_step, pools, steps, warmup, sync):
@@ -364,6 +422,15 @@ def main(argv=None):
         stage_ms["sort_algorithmic_gbs"] = round(sort_bytes / (ms_per_step * 1e-3) / 1e9, 1) if not distributed else None
         stage_ms["sort_roofline_frac"] = round(sort_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if not distributed else None
         roofline["rank_method"] = lsd.rank_method(r)
+        if not distributed and not args.no_live_traffic and args.algorithm == "onesweep" and args.tile_config < 0:
+            live = live_pmc_traffic(r, args.pairs, log2_keys)
+            if live is not None:
+                roofline["traffic"] = live["bytes"]
+                roofline["traffic_source"] = ("measured in this run: two separate rocprofv3 --pmc passes (FETCH_SIZE x 2, WRITE_SIZE; KiB) over "
+                                              f"child processes running the same sort on the same input (tools/prof_target.py), {live['launches']} launches, "
+                                              f"kernel {live['kernel_us_under_profiler']} us under the profiler; FETCH_SIZE x 2 on the histogram kernel's "
+                                              f"known 4n read: ratio {live['calibration_ratio']}")
+                roofline["traffic_over_algorithmic"] = round(live["bytes"] / roofline["algorithmic_bytes_per_launch"], 4)
 
     # ---- secondary configs on the same box (N=1 only): configs[1] (r=4) and configs[4] (pairs), stage rows ----
     extra = {}
