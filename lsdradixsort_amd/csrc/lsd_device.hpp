@@ -74,15 +74,30 @@ __device__ __forceinline__ uint64_t match_ballot(uint32_t d)
     return m;
 }
 
-// Inclusive scan across the 64 lanes of a wave.
+// Inclusive scan across the 64 lanes of a wave, on the DPP network (no LDS round trips): row_shr 1/2/4/8 scans the four
+// rows of 16 lanes, row_bcast15 carries row 0's total into row 1 and row 2's into row 3, row_bcast31 carries the first
+// half's total into the second (the sequence LLVM's atomic optimiser emits for wave64 on GFX9-family targets).
+// -DLSD_SCAN_SHFL builds the ds_bpermute (__shfl_up) form this replaced (A/B in DESIGN.md section 4.8).
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
 {
+#ifdef LSD_SCAN_SHFL
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
         const uint32_t up = __shfl_up(v, off, kWave);
         if (lane >= (uint32_t)off) v += up;
     }
     return v;
+#else
+    (void)lane;
+    // update_dpp(old, src, dpp_ctrl, row_mask, bank_mask, bound_ctrl): lanes without a source keep `old` = 0
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
+    return v;
+#endif
 }
 
 // Number of LDS replicas of a small histogram so that 64 lanes do not pile onto a handful
