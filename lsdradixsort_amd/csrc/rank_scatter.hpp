@@ -42,6 +42,7 @@
 #include "lsd_device.hpp"
 #include "lsd_kernels.hpp"
 #include <cstdio>
+#include <type_traits>
 #include <hip/hip_ext.h>
 
 namespace lsd {
@@ -613,39 +614,54 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             // behind those stores (where the payloads are used) would also wait for every store's acknowledgement.
 #pragma unroll
             for (int i = 0; i < K; i++) asm volatile("" : "+v"(val[i]));
+            // `full` (every tile but a region's last) is tested ONCE, outside the slot loops: a test per slot puts every slot
+            // into a basic block of its own, and the s_gdelta read of each is then waited for (lgkmcnt(0)) before the next
+            // is issued -- 32 dependent LDS round trips per thread instead of one batch.
+            auto key_slots = [&](auto all_valid) {
 #pragma unroll
-            for (int s2 = 0; s2 < SLOTS; s2++) {
-                const uint32_t slot = s2 * T + tid;
-                const uint32_t q = round * CAP + slot;
-                const uint32_t k = s_keys[slot];
-                const uint32_t d = digit_of(k);
-                if ((s2 & 3) == 0) dbytes[s2 / 4] = d;
-                else dbytes[s2 / 4] |= d << (8 * (s2 & 3));
-                if (full || q < valid) p.out[s_gdelta[d] + q] = leaving(k);
-                if ((s2 & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep at most eight slots in flight
-            }
-        } else if (PREREAD) {
-#pragma unroll
-            for (int s2 = 0; s2 < SLOTS; s2++) {
-                const uint32_t q = s2 * T + tid;
-                const uint32_t k = back[PREREAD ? s2 : 0];
-                const uint32_t d = digit_of(k);
-                if (full || q < valid) p.out[s_gdelta[d] + q] = leaving(k);
-            }
-        } else {
-            // keys only: sixteen slots at a time, which bounds the registers of the read-back
-            constexpr int STEP = SLOTS < 16 ? SLOTS : 16;
-#pragma unroll 1
-            for (int s0 = 0; s0 < SLOTS; s0 += STEP) {
-#pragma unroll
-                for (int u = 0; u < STEP; u++) {
-                    const uint32_t slot = (s0 + u) * T + tid;
+                for (int s2 = 0; s2 < SLOTS; s2++) {
+                    const uint32_t slot = s2 * T + tid;
                     const uint32_t q = round * CAP + slot;
                     const uint32_t k = s_keys[slot];
                     const uint32_t d = digit_of(k);
-                    if (full || q < valid) p.out[s_gdelta[d] + q] = leaving(k);
+                    if ((s2 & 3) == 0) dbytes[s2 / 4] = d;
+                    else dbytes[s2 / 4] |= d << (8 * (s2 & 3));
+                    if (decltype(all_valid)::value || q < valid) p.out[s_gdelta[d] + q] = leaving(k);
+                    if ((s2 & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep at most eight slots in flight
                 }
-            }
+            };
+            if (full) key_slots(std::true_type{});
+            else key_slots(std::false_type{});
+        } else if (PREREAD) {
+            auto key_slots = [&](auto all_valid) {
+#pragma unroll
+                for (int s2 = 0; s2 < SLOTS; s2++) {
+                    const uint32_t q = s2 * T + tid;
+                    const uint32_t k = back[PREREAD ? s2 : 0];
+                    const uint32_t d = digit_of(k);
+                    if (decltype(all_valid)::value || q < valid) p.out[s_gdelta[d] + q] = leaving(k);
+                }
+            };
+            if (full) key_slots(std::true_type{});
+            else key_slots(std::false_type{});
+        } else {
+            // keys only: sixteen slots at a time, which bounds the registers of the read-back
+            constexpr int STEP = SLOTS < 16 ? SLOTS : 16;
+            auto key_slots = [&](auto all_valid) {
+#pragma unroll 1
+                for (int s0 = 0; s0 < SLOTS; s0 += STEP) {
+#pragma unroll
+                    for (int u = 0; u < STEP; u++) {
+                        const uint32_t slot = (s0 + u) * T + tid;
+                        const uint32_t q = round * CAP + slot;
+                        const uint32_t k = s_keys[slot];
+                        const uint32_t d = digit_of(k);
+                        if (decltype(all_valid)::value || q < valid) p.out[s_gdelta[d] + q] = leaving(k);
+                    }
+                }
+            };
+            if (full) key_slots(std::true_type{});
+            else key_slots(std::false_type{});
         }
 
         // ---- 6. payloads follow their keys through the same slots -----------------------------
@@ -656,14 +672,18 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                 if (ROUNDS == 1 || (pos_at(i) / (uint32_t)CAP) == (uint32_t)round) s_keys[pos_at(i) % (uint32_t)CAP] = val[i];
             }
             lds_barrier();
+            auto val_slots = [&](auto all_valid) {
 #pragma unroll
-            for (int s2 = 0; s2 < SLOTS; s2++) {
-                const uint32_t slot = s2 * T + tid;
-                const uint32_t q = round * CAP + slot;
-                const uint32_t d = (dbytes[s2 / 4] >> (8 * (s2 & 3))) & 0xFFu;
-                if (full || q < valid) p.vals_out[s_gdelta[d] + q] = s_keys[slot];
-                if ((s2 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-            }
+                for (int s2 = 0; s2 < SLOTS; s2++) {
+                    const uint32_t slot = s2 * T + tid;
+                    const uint32_t q = round * CAP + slot;
+                    const uint32_t d = (dbytes[s2 / 4] >> (8 * (s2 & 3))) & 0xFFu;
+                    if (decltype(all_valid)::value || q < valid) p.vals_out[s_gdelta[d] + q] = s_keys[slot];
+                    if ((s2 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (full) val_slots(std::true_type{});
+            else val_slots(std::false_type{});
         }
     }
 #ifdef LSD_PHASE_STATS
