@@ -528,6 +528,11 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                 uint32_t gbase;
                 if (CHAINED) {
                     uint32_t excl = 0;
+                    // region_base was loaded together with the first look-back step: take it HERE, on every path.  Its first
+                    // use sits behind the prefix store below, and a wave's memory operations retire in issue order: the
+                    // compiler's wait for it there (vmcnt(0) at the join of the paths) also sat out the store's
+                    // acknowledgement, with every other wave of the tile parked at the barrier that follows.
+                    asm volatile("" : "+v"(region_base));
                     if (chain_pos > 0) {
                         // first step: own window, then the helper slots' rows, in chain order
                         int consumed = 0;
