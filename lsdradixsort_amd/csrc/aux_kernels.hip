@@ -631,7 +631,22 @@ __global__ void __launch_bounds__(T) tile_histograms_kernel(const uint32_t* __re
     __syncthreads();
     const uint32_t begin = blockIdx.x * tile_keys;
     const uint32_t end = (n - begin < tile_keys) ? n : begin + tile_keys;
-    for (uint32_t i = begin + tid; i < end; i += T) atomicAdd(&s_hist[digit_at<R>(keys[i], shift) * C + copy], 1u);
+    // 16-byte loads over the tile's body when the tile starts on a 16-byte boundary (tile sizes are multiples of four keys,
+    // so it does whenever the array does); the few keys behind the last whole vector, or everything otherwise, one by one
+    uint32_t scalar_from = begin;
+    if ((reinterpret_cast<uintptr_t>(keys + begin) & 15u) == 0) {
+        const uint4* __restrict__ v4 = reinterpret_cast<const uint4*>(keys + begin);
+        const uint32_t vecs = (end - begin) / 4u;
+        for (uint32_t v = tid; v < vecs; v += T) {
+            const uint4 k = v4[v];
+            atomicAdd(&s_hist[digit_at<R>(k.x, shift) * C + copy], 1u);
+            atomicAdd(&s_hist[digit_at<R>(k.y, shift) * C + copy], 1u);
+            atomicAdd(&s_hist[digit_at<R>(k.z, shift) * C + copy], 1u);
+            atomicAdd(&s_hist[digit_at<R>(k.w, shift) * C + copy], 1u);
+        }
+        scalar_from = begin + vecs * 4u;
+    }
+    for (uint32_t i = scalar_from + tid; i < end; i += T) atomicAdd(&s_hist[digit_at<R>(keys[i], shift) * C + copy], 1u);
     __syncthreads();
     for (uint32_t d = tid; d < (uint32_t)H; d += T) {
         uint32_t sum = 0;

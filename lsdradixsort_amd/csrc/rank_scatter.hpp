@@ -426,10 +426,14 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     if (H > kWave) {
         if (lane == 63u) s_misc[1 + wave] = incl;
         lds_barrier();
+        // all wave totals are read as one batch and selected afterwards: a read per `if` is a basic block of its own
+        // with its own lgkmcnt(0), i.e. H / 64 dependent LDS round trips on the tile's critical path
+        uint32_t part[(H / kWave) > 0 ? H / kWave : 1];
+#pragma unroll
+        for (int w = 0; w < H / kWave; w++) part[w] = s_misc[1 + w];
         uint32_t carry = 0;
 #pragma unroll
-        for (int w = 0; w < H / kWave; w++)
-            if ((uint32_t)w < wave) carry += s_misc[1 + w];
+        for (int w = 0; w < H / kWave; w++) carry += (uint32_t)w < wave ? part[w] : 0u;
         incl += carry;
     }
     const uint32_t local_off = incl - total;   // exclusive scan over digits
