@@ -407,12 +407,15 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
         uint4 nxt[VPT];
         const uint32_t cn = c + stride;
         if (cn < vec_chunks) load_group(cn, nxt);
+        // one look per group of VPT vectors (its first key) decides which path the group takes: both paths count every
+        // key exactly, the choice is speed only, and the test itself is a sixth of the plain path's instructions
+        const bool checked = looks_uniform(cur[0].x);
 #pragma unroll
         for (int u = 0; u < VPT; u++) {
             if (c + u < vec_chunks) {
                 // region0_keys is a multiple of the chunk (THREADS*4 keys), so the chunk is in one region
                 const uint32_t region0 = ((chunk_base + c + u) * (uint32_t)(THREADS * 4)) / region0_keys;
-                if (looks_uniform(cur[u].x)) {
+                if (checked) {
                     count_vec_checked(cur[u], region0);
                 } else {
                     count_key_plain(cur[u].x, region0);

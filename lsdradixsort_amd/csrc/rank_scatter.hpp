@@ -502,7 +502,8 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         if (round > 0) lds_barrier();   // the previous round has been read back
 #pragma unroll
         for (int i = 0; i < K; i++) {
-            if (ROUNDS == 1 || (pos_at(i) / (uint32_t)CAP) == (uint32_t)round) s_keys[pos_at(i) % (uint32_t)CAP] = key[i];
+            if (ROUNDS == 1) s_keys[pos_at(i)] = key[i];      // one round: every position is below CAP
+            else if ((pos_at(i) / (uint32_t)CAP) == (uint32_t)round) s_keys[pos_at(i) % (uint32_t)CAP] = key[i];
         }
         if (PAIRS && ROUNDS == 1) load_vals();   // the key registers are free now
         // One workgroup per CU (the 32768-key tile), keys only: nothing else runs on the CU while this
@@ -678,7 +679,8 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             lds_barrier();   // every key of this round has been read back
 #pragma unroll
             for (int i = 0; i < K; i++) {
-                if (ROUNDS == 1 || (pos_at(i) / (uint32_t)CAP) == (uint32_t)round) s_keys[pos_at(i) % (uint32_t)CAP] = val[i];
+                if (ROUNDS == 1) s_keys[pos_at(i)] = val[i];
+                else if ((pos_at(i) / (uint32_t)CAP) == (uint32_t)round) s_keys[pos_at(i) % (uint32_t)CAP] = val[i];
             }
             lds_barrier();
             auto val_slots = [&](auto all_valid) {
