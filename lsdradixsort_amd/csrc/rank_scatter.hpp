@@ -290,12 +290,39 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
 
     // ---- 1. load: wave-striped, so (register row, lane) order == key order ------------------------
     uint32_t key[K];
+    uint32_t rank[K];
+    bool ranked = false;   // wave-uniform: the full-tile fast path below has already ranked this wave's keys
     const uint32_t first = tile_base + wave * (uint32_t)(kWave * K) + lane;
     // one 64-bit base, constant offsets: an index sum per load would cost an address pair per load
     const uint32_t* const keys_in = p.in + first;
     if (full) {
 #pragma unroll
         for (int i = 0; i < K; i++) key[i] = keys_in[i * kWave];
+#ifndef LSD_NO_RANK_HALVES   // (-DLSD_NO_RANK_HALVES builds the form that waits for every load first: +1.3 % kernel time)
+        // Full tile, returning-LDS-add rank, no key transform: rank the first half of the rows as soon as THEIR loads are
+        // in (the loads retire in issue order) and the second half behind a second wait, in the basic block of the loads --
+        // behind the join with the tail-tile path the compiler can only wait for everything (vmcnt(0)).
+        if constexpr (RANK == kRankLdsAdd && K >= 16 && !XF) {
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(K - K / 2) : "memory");
+            const uint32_t d_first = digit_of(key[0]);
+            if (!__all(d_first == __builtin_amdgcn_readfirstlane(d_first))) {
+#pragma unroll
+                for (int i = 0; i < K / 2; i++)
+                    rank[i] = __hip_atomic_fetch_add((lds_u32*)&s_cnt[wave * H + digit_of(key[i])], 1u, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WAVEFRONT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // the second half's keys become usable only here: without this their digit extraction is hoisted above
+                // the first half's atomics, and the wait for them with it
+#pragma unroll
+                for (int i = K / 2; i < K; i++) asm volatile("" : "+v"(key[i]));
+#pragma unroll
+                for (int i = K / 2; i < K; i++)
+                    rank[i] = __hip_atomic_fetch_add((lds_u32*)&s_cnt[wave * H + digit_of(key[i])], 1u, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WAVEFRONT);
+                ranked = true;
+            }
+        }
+#endif
     } else {
 #pragma unroll
         for (int i = 0; i < K; i++) {
@@ -317,8 +344,9 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LSD_STAMP(1);   // key load
 #endif
-    uint32_t rank[K];
-    if (RANK == kRankLdsAdd) {
+    if (ranked) {
+        // done above
+    } else if (RANK == kRankLdsAdd) {
         // The returned old value is (same-digit keys in earlier rows) + (peers in lower lanes):
         // the K atomics are independent, so they issue back to back.
         // A row whose 64 keys share one digit (constant or sorted input, dead digits) would
