@@ -383,8 +383,11 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
         return any;
     };
 
-    // Software-pipelined: the next group of 16-byte loads is in flight while the current group's
-    // keys go through the LDS atomics, so the memory pipe and the LDS stay busy together.
+    // Software-pipelined with TWO register buffers that swap roles (the loop is unrolled by two): while one group of
+    // 16-byte loads goes through the LDS atomics the next is in flight, and the wait in front of a group is a COUNTED one
+    // (`vmcnt(VPT)`: everything but the loads just issued).  The round-1 form copied `next` into `current` at the loop's
+    // end; at the join of the loop's paths the compiler then waited for every outstanding load (`vmcnt(0)`) before touching
+    // `current` -- i.e. for the loads it had just issued: nothing was in flight while a wave counted.
     constexpr int VPT = kHistVecPerThread;
     const uint4* __restrict__ keys4 = reinterpret_cast<const uint4*>(keys);
     auto load_group = [&](uint32_t c, uint4 (&v)[VPT]) {
@@ -393,41 +396,48 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
             const uint32_t cc = c + u;
             v[u] = cc < vec_chunks ? keys4[(size_t)cc * THREADS + tid] : make_uint4(0, 0, 0, 0);
         }
-        if (xf.on) {   // typed sorts count the "sortable" form of the keys (uniform branch)
+    };
+    auto count_group = [&](uint32_t c, uint4 (&v)[VPT]) {
+        if (xf.on) {   // typed sorts count the "sortable" form of the keys (uniform branch); applied where the keys are used
 #pragma unroll
             for (int u = 0; u < VPT; u++)
                 v[u] = make_uint4(to_sortable(v[u].x, xf), to_sortable(v[u].y, xf), to_sortable(v[u].z, xf), to_sortable(v[u].w, xf));
         }
-    };
-    const uint32_t stride = gridDim.x * VPT;
-    uint32_t c = blockIdx.x * VPT;
-    uint4 cur[VPT];
-    if (c < vec_chunks) load_group(c, cur);
-    while (c < vec_chunks) {
-        uint4 nxt[VPT];
-        const uint32_t cn = c + stride;
-        if (cn < vec_chunks) load_group(cn, nxt);
         // one look per group of VPT vectors (its first key) decides which path the group takes: both paths count every
         // key exactly, the choice is speed only, and the test itself is a sixth of the plain path's instructions
-        const bool checked = looks_uniform(cur[0].x);
+        const bool checked = looks_uniform(v[0].x);
 #pragma unroll
         for (int u = 0; u < VPT; u++) {
             if (c + u < vec_chunks) {
                 // region0_keys is a multiple of the chunk (THREADS*4 keys), so the chunk is in one region
                 const uint32_t region0 = ((chunk_base + c + u) * (uint32_t)(THREADS * 4)) / region0_keys;
                 if (checked) {
-                    count_vec_checked(cur[u], region0);
+                    count_vec_checked(v[u], region0);
                 } else {
-                    count_key_plain(cur[u].x, region0);
-                    count_key_plain(cur[u].y, region0);
-                    count_key_plain(cur[u].z, region0);
-                    count_key_plain(cur[u].w, region0);
+                    count_key_plain(v[u].x, region0);
+                    count_key_plain(v[u].y, region0);
+                    count_key_plain(v[u].z, region0);
+                    count_key_plain(v[u].w, region0);
                 }
             }
         }
-#pragma unroll
-        for (int u = 0; u < VPT; u++) cur[u] = nxt[u];
-        c = cn;
+    };
+    const uint32_t stride = gridDim.x * VPT;
+    uint32_t c = blockIdx.x * VPT;
+    if (c < vec_chunks) {
+        uint4 buf_a[VPT], buf_b[VPT];
+        load_group(c, buf_a);
+        for (;;) {
+            const uint32_t c1 = c + stride;
+            if (c1 < vec_chunks) load_group(c1, buf_b);
+            count_group(c, buf_a);
+            if (c1 >= vec_chunks) break;
+            const uint32_t c2 = c1 + stride;
+            if (c2 < vec_chunks) load_group(c2, buf_a);
+            count_group(c1, buf_b);
+            if (c2 >= vec_chunks) break;
+            c = c2;
+        }
     }
     {
         // tail -- or every key when the base is not 16-byte aligned (vec_chunks == 0) -- strided over the grid;
