@@ -538,7 +538,14 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         // tile waits for its predecessors, so fetch the tile-ordered keys back from LDS BEFORE the
         // look-back is consumed and leave only destination lookups and stores behind it (+0.7 %; with
         // two workgroups per CU the extra barrier costs more than it hides: -1.5 %).
+        // Round 1 kept this on for the 32768-key tile (+0.7 % then).  Since the read-back issues its destination-base reads in
+        // batches (round 2) it LOSES 0.9 % (kernel 1.9 %): the slots' LDS reads now overlap the stores anyway, and the 32
+        // registers it holds across the look-back are better spent there.  -DLSD_PREREAD builds it.
+#ifdef LSD_PREREAD
         constexpr bool PREREAD = !PAIRS && ROUNDS == 1 && TILE >= 32768;
+#else
+        constexpr bool PREREAD = false;
+#endif
         uint32_t back[PREREAD ? SLOTS : 1];
         if (PREREAD) {
             lds_barrier();   // the whole tile is in LDS
@@ -684,7 +691,10 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             else key_slots(std::false_type{});
         } else {
             // keys only: sixteen slots at a time, which bounds the registers of the read-back
-            constexpr int STEP = SLOTS < 16 ? SLOTS : 16;
+#ifndef LSD_READBACK_STEP
+#define LSD_READBACK_STEP 4   // slots per batch 4 / 8 / 16 / 32: 2.016 / 2.032 (2.020) / 2.035 / 2.037 ms per sort (tools/ab_bench.sh, six interleaved runs each)
+#endif
+            constexpr int STEP = SLOTS < LSD_READBACK_STEP ? SLOTS : LSD_READBACK_STEP;
             auto key_slots = [&](auto all_valid) {
 #pragma unroll 1
                 for (int s0 = 0; s0 < SLOTS; s0 += STEP) {
