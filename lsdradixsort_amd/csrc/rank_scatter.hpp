@@ -303,22 +303,30 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         // in (the loads retire in issue order) and the second half behind a second wait, in the basic block of the loads --
         // behind the join with the tail-tile path the compiler can only wait for everything (vmcnt(0)).
         if constexpr (RANK == kRankLdsAdd && K >= 16 && !XF) {
-            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(K - K / 2) : "memory");
+#ifndef LSD_RANK_BATCHES
+#define LSD_RANK_BATCHES 2
+#endif
+            constexpr int NB = LSD_RANK_BATCHES, PER = K / NB;
+            static_assert(K % NB == 0, "batches divide the rows");
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(K - PER) : "memory");
             const uint32_t d_first = digit_of(key[0]);
             if (!__all(d_first == __builtin_amdgcn_readfirstlane(d_first))) {
 #pragma unroll
-                for (int i = 0; i < K / 2; i++)
-                    rank[i] = __hip_atomic_fetch_add((lds_u32*)&s_cnt[wave * H + digit_of(key[i])], 1u, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_WAVEFRONT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                // the second half's keys become usable only here: without this their digit extraction is hoisted above
-                // the first half's atomics, and the wait for them with it
+                for (int b = 0; b < NB; b++) {
+                    if (b > 0) {
+                        // batch b's keys become usable only behind its own wait: without the pins their digit extraction is
+                        // hoisted above the earlier batches' atomics, and the wait for them with it
+                        if (b == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(K - 2 * PER < 0 ? 0 : K - 2 * PER) : "memory");
+                        else if (b == 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(K - 3 * PER < 0 ? 0 : K - 3 * PER) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int i = K / 2; i < K; i++) asm volatile("" : "+v"(key[i]));
+                        for (int i = b * PER; i < (b + 1) * PER; i++) asm volatile("" : "+v"(key[i]));
+                    }
 #pragma unroll
-                for (int i = K / 2; i < K; i++)
-                    rank[i] = __hip_atomic_fetch_add((lds_u32*)&s_cnt[wave * H + digit_of(key[i])], 1u, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    for (int i = b * PER; i < (b + 1) * PER; i++)
+                        rank[i] = __hip_atomic_fetch_add((lds_u32*)&s_cnt[wave * H + digit_of(key[i])], 1u, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
                 ranked = true;
             }
         }
