@@ -699,10 +699,17 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             else key_slots(std::false_type{});
         } else {
             // keys only: sixteen slots at a time, which bounds the registers of the read-back
-#ifndef LSD_READBACK_STEP
-#define LSD_READBACK_STEP 4   // slots per batch 4 / 8 / 16 / 32: 2.016 / 2.032 (2.020) / 2.035 / 2.037 ms per sort (tools/ab_bench.sh, six interleaved runs each)
+            // slots per batch.  One 16-wave workgroup per CU (1024 threads): 2 / 4 / 8 / 16 / 32 slots measure 2.006 / 2.011-2.016 /
+            // 2.032 / 2.035 / 2.037 ms per 2^28-key sort and 1 slot 2.082 (small batches let a batch's LDS reads overlap the
+            // stores of the one before; a single slot is two dependent LDS round trips with every wave of the CU in the same
+            // phase).  With two 8-wave workgroups per CU (512 threads) the OTHER workgroup is what overlaps, and one slot at
+            // a time is fastest (table-driven pass, 512 x 32 tile: 1 / 2 / 4 / 16 slots 0.430 / 0.437 / 0.456 / 0.467 ms).
+#ifdef LSD_READBACK_STEP
+            constexpr int STEP_WANTED = LSD_READBACK_STEP;
+#else
+            constexpr int STEP_WANTED = T >= 1024 ? 4 : 1;
 #endif
-            constexpr int STEP = SLOTS < LSD_READBACK_STEP ? SLOTS : LSD_READBACK_STEP;
+            constexpr int STEP = SLOTS < STEP_WANTED ? SLOTS : STEP_WANTED;
             auto key_slots = [&](auto all_valid) {
 #pragma unroll 1
                 for (int s0 = 0; s0 < SLOTS; s0 += STEP) {
