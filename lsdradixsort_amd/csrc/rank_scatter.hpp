@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     const uint32_t my_digit = tid % (uint32_t)H;
     const uint32_t my_slot = tid / (uint32_t)H;
     const uint32_t* const status_col = CHAINED ? p.status + (size_t)chain_row0 * H + my_digit : nullptr;
-    uint32_t window[LB];
+    uint32_t window[LB] = {};
     int32_t j = (int32_t)chain_pos - 1;   // nearest predecessor in the chain not yet consumed
     uint32_t region_base = 0;   // where this region's keys of digit `tid` start in the output
     auto first_step = [&]() {
@@ -572,15 +572,20 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                 }
                 lds_barrier();
             }
+            if (CHAINED) {
+                // region_base and the first look-back step were loaded before the LDS writes: take them HERE, by every
+                // thread, ahead of the branch.  A wave's memory operations retire in issue order, so wherever the
+                // compiler places its wait for them it waits for everything older too: left to itself it waited at
+                // the join BEHIND the digit threads' block (the registers are reused there), and so sat out the
+                // acknowledgement of the prefix store inside it before the wave could start on its key stores.
+                asm volatile("" : "+v"(region_base));
+#pragma unroll
+                for (int l = 0; l < LB; l++) asm volatile("" : "+v"(window[l]));
+            }
             if (tid < (uint32_t)H) {
                 uint32_t gbase;
                 if (CHAINED) {
                     uint32_t excl = 0;
-                    // region_base was loaded together with the first look-back step: take it HERE, on every path.  Its first
-                    // use sits behind the prefix store below, and a wave's memory operations retire in issue order: the
-                    // compiler's wait for it there (vmcnt(0) at the join of the paths) also sat out the store's
-                    // acknowledgement, with every other wave of the tile parked at the barrier that follows.
-                    asm volatile("" : "+v"(region_base));
                     if (chain_pos > 0) {
                         // first step: own window, then the helper slots' rows, in chain order
                         int consumed = 0;
@@ -652,9 +657,10 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         }
         lds_barrier();
         if (round == 0) LSD_STAMP(5);   // look-back (wave 0's digits) + barrier
-        if (round == 0) clear_next();   // no load of this wave is waited for from here on
-        if (CHAINED && round == 0 && s_misc[30] != 0u) return;   // the look-back gave up (uniform): the sort has failed
-                                                               // (fault word set); store nothing from a base that is not known
+        if (CHAINED && round == 0 && s_misc[30] != 0u) {   // the look-back gave up (uniform): the sort has failed (fault word
+            clear_next();                                  // set); store nothing from a base that is not known
+            return;
+        }
 
         // linear read-back: consecutive threads hold consecutive tile positions, so each digit's
         // keys leave as one contiguous run
@@ -750,6 +756,10 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             else val_slots(std::false_type{});
         }
     }
+    // Housekeeping for the next pass goes LAST: nothing is waited for behind it.  (Placed in front of the read-back, as
+    // in round 1, the compiler's vmcnt(0) at the join behind its store loop made the four waves that hold the digit threads
+    // sit out these stores' acknowledgements before their first key store.)
+    clear_next();
 #ifdef LSD_PHASE_STATS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LSD_STAMP(6);   // read-back + stores drained
