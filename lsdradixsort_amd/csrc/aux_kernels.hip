@@ -269,7 +269,11 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
     // Counter of a field value, bank-swizzled: the low five index bits (the LDS bank) are XORed with the
     // next five.  Few-valued digits (16 values per byte: text, small alphabets) give field values that
     // are multiples of 8 -- four banks for the whole wave without this (0.81 ms instead of 0.27).
+#ifdef LSD_HIST_NO_SWIZZLE
+    auto word = [&](uint32_t slot) -> uint32_t& { return s_joint[slot * C]; };
+#else
     auto word = [&](uint32_t slot) -> uint32_t& { return s_joint[(slot ^ ((slot >> 5) & 31u)) * C]; };
+#endif
 
     // Low-entropy fields (constant or sorted input, dead high digits) would serialise all 64 lanes
     // of a wave on one LDS word; when the whole wave agrees on a field, one lane adds 64 instead.
@@ -385,17 +389,18 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
 
     // Software-pipelined with TWO register buffers that swap roles (the loop is unrolled by two): while one group of
     // 16-byte loads goes through the LDS atomics the next is in flight, and the wait in front of a group is a COUNTED one
-    // (`vmcnt(VPT)`: everything but the loads just issued).  The round-1 form copied `next` into `current` at the loop's
-    // end; at the join of the loop's paths the compiler then waited for every outstanding load (`vmcnt(0)`) before touching
-    // `current` -- i.e. for the loads it had just issued: nothing was in flight while a wave counted.
+    // (`vmcnt(VPT)`: everything but the loads just issued).  For the compiler to count, the loads and the group they overtake
+    // must sit in ONE straight line: its wait-count pass merges paths conservatively, so a load behind a branch of its own
+    // (an `if (chunk < end)` per load, an `if (more) load_group()` per group -- rounds 1 and 2 had both) turned the wait into
+    // `vmcnt(0)`, i.e. into waiting for the loads just issued, with nothing in flight while a wave counted.  So the loop takes
+    // FULL groups only and always loads: past its last group a workgroup reloads the group it already holds (an L2 hit)
+    // and does not count it.  Chunks beyond the last full group go with the tail below.
     constexpr int VPT = kHistVecPerThread;
     const uint4* __restrict__ keys4 = reinterpret_cast<const uint4*>(keys);
+    const uint32_t full_chunks = vec_chunks / VPT * VPT;
     auto load_group = [&](uint32_t c, uint4 (&v)[VPT]) {
 #pragma unroll
-        for (int u = 0; u < VPT; u++) {
-            const uint32_t cc = c + u;
-            v[u] = cc < vec_chunks ? keys4[(size_t)cc * THREADS + tid] : make_uint4(0, 0, 0, 0);
-        }
+        for (int u = 0; u < VPT; u++) v[u] = keys4[(size_t)(c + u) * THREADS + tid];
     };
     auto count_group = [&](uint32_t c, uint4 (&v)[VPT]) {
         if (xf.on) {   // typed sorts count the "sortable" form of the keys (uniform branch); applied where the keys are used
@@ -408,41 +413,42 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
         const bool checked = looks_uniform(v[0].x);
 #pragma unroll
         for (int u = 0; u < VPT; u++) {
-            if (c + u < vec_chunks) {
-                // region0_keys is a multiple of the chunk (THREADS*4 keys), so the chunk is in one region
-                const uint32_t region0 = ((chunk_base + c + u) * (uint32_t)(THREADS * 4)) / region0_keys;
-                if (checked) {
-                    count_vec_checked(v[u], region0);
-                } else {
-                    count_key_plain(v[u].x, region0);
-                    count_key_plain(v[u].y, region0);
-                    count_key_plain(v[u].z, region0);
-                    count_key_plain(v[u].w, region0);
-                }
+            // region0_keys is a multiple of the chunk (THREADS*4 keys), so the chunk is in one region
+            const uint32_t region0 = ((chunk_base + c + u) * (uint32_t)(THREADS * 4)) / region0_keys;
+            if (checked) {
+                count_vec_checked(v[u], region0);
+            } else {
+                count_key_plain(v[u].x, region0);
+                count_key_plain(v[u].y, region0);
+                count_key_plain(v[u].z, region0);
+                count_key_plain(v[u].w, region0);
             }
         }
     };
     const uint32_t stride = gridDim.x * VPT;
     uint32_t c = blockIdx.x * VPT;
-    if (c < vec_chunks) {
+    if (c < full_chunks) {
         uint4 buf_a[VPT], buf_b[VPT];
         load_group(c, buf_a);
         for (;;) {
             const uint32_t c1 = c + stride;
-            if (c1 < vec_chunks) load_group(c1, buf_b);
+            const bool more1 = c1 < full_chunks;
+            load_group(more1 ? c1 : c, buf_b);
             count_group(c, buf_a);
-            if (c1 >= vec_chunks) break;
+            if (!more1) break;
             const uint32_t c2 = c1 + stride;
-            if (c2 < vec_chunks) load_group(c2, buf_a);
+            const bool more2 = c2 < full_chunks;
+            load_group(more2 ? c2 : c1, buf_a);
             count_group(c1, buf_b);
-            if (c2 >= vec_chunks) break;
+            if (!more2) break;
             c = c2;
         }
     }
     {
-        // tail -- or every key when the base is not 16-byte aligned (vec_chunks == 0) -- strided over the grid;
-        // a step's keys are consecutive, so a wave stays inside one pass-0 region except at a boundary
-        const uint32_t tail_begin = vec_chunks * (THREADS * 4);
+        // tail: the chunks past the last full group and the keys past the last chunk -- or every key when the base is not
+        // 16-byte aligned (vec_chunks == 0) -- strided over the grid; a step's keys are consecutive, so a wave stays inside
+        // one pass-0 region except at a boundary
+        const uint32_t tail_begin = full_chunks * (THREADS * 4);
         for (size_t i = (size_t)tail_begin + (size_t)blockIdx.x * THREADS + tid; i < n; i += (size_t)gridDim.x * THREADS)
             count_key_checked(xf.on ? to_sortable(keys[i], xf) : keys[i], (uint32_t)((first_key + i) / region0_keys));
     }
