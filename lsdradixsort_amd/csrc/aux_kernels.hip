@@ -24,7 +24,10 @@ namespace lsd {
 // or sixteen words), streams keys with 16-byte loads, and flushes once with global atomics.
 // ------------------------------------------------------------------------------------------
 constexpr int kHistThreads = 256;
-constexpr int kHistVecPerThread = 4;   // uint4 loads in flight per thread per iteration
+#ifndef LSD_HIST_VPT
+#define LSD_HIST_VPT 4
+#endif
+constexpr int kHistVecPerThread = LSD_HIST_VPT;   // uint4 loads in flight per thread per iteration
 
 template <int R, int G>
 __global__ void __launch_bounds__(kHistThreads) digit_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
@@ -298,6 +301,7 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
 #pragma unroll
         for (int p = 1; p < P; p++) add_field_checked(p * F + digit_at<R + B>(k, (uint32_t)(R * p - B)));
     };
+    [[maybe_unused]] uint32_t probe_acc = 0;   // -DLSD_HIST_PROBE_NOATOMIC only
     auto count_key_plain = [&](uint32_t k, uint32_t region0) {
         if (WIDE) {
             atomicAdd(&word((region0 << 8) | (k & 0xFFu)), 1u);
@@ -305,6 +309,13 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
             for (int j = 1; j < NF; j++) atomicAdd(&word(j * FW + digit_at<12>(k, (uint32_t)(8 * j - 4))), 1u);
             return;
         }
+#ifdef LSD_HIST_PROBE_NOATOMIC   // timing probe only (wrong counts): the address arithmetic without the LDS operations
+        probe_acc += (uint32_t)(uintptr_t)(&word((region0 << R) | digit_at<R>(k, 0)) + copy);
+#pragma unroll
+        for (int p = 1; p < P; p++)
+            probe_acc ^= (uint32_t)(uintptr_t)(&word(p * F + digit_at<R + B>(k, (uint32_t)(R * p - B))) + copy);
+        return;
+#endif
         atomicAdd(&word((region0 << R) | digit_at<R>(k, 0)) + copy, 1u);
 #pragma unroll
         for (int p = 1; p < P; p++)
@@ -452,6 +463,9 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
         for (size_t i = (size_t)tail_begin + (size_t)blockIdx.x * THREADS + tid; i < n; i += (size_t)gridDim.x * THREADS)
             count_key_checked(xf.on ? to_sortable(keys[i], xf) : keys[i], (uint32_t)((first_key + i) / region0_keys));
     }
+#ifdef LSD_HIST_PROBE_NOATOMIC
+    if (probe_acc == 0x12345u) s_joint[tid] = probe_acc;
+#endif
     __syncthreads();
     // Flush.  Pass 0's fields sit region-major in LDS: all 64 lanes of a wave share their position
     // region, so with the region in the low index bits they would share four LDS banks; the global
