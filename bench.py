@@ -322,44 +322,37 @@ def main(argv=None):
     else:
         from lsdradixsort_amd.dist import HipBackend, ShardedSorter, distributed_sort
 
+        # The product path: the C++ step behind the C-ABI (lsdsort_sharded_u32_device_ex), RCCL called from C++, with
+        # either ownership rule (--partition msb | splitters).  It is built and proved once on a small array before
+        # anything is timed; if ANY rank fails there (its own librccl cannot be loaded or refuses the communicator),
+        # every rank switches to the torch.distributed driver over the same kernels and the JSON line says so -- a
+        # number from the other path, not no number.
         exchange_path = "c++"
-        if args.partition == "msb":
-            # The product path: the C++ step behind the C-ABI (lsdsort_sharded_u32_device), RCCL called from C++.
-            # It is built and proved once on a small array before anything is timed; if ANY rank fails there (its own
-            # librccl cannot be loaded or refuses the communicator), every rank switches to the torch.distributed
-            # driver over the same kernels and the JSON line says so -- a number from the other path, not no number.
-            backend, why = None, ""
-            try:
-                backend = ShardedSorter(r)
-                probe = backend.sort(master[: min(n, 1 << 16)].clone())
-                torch.cuda.synchronize()
-                if backend.check_fault() != 0:
-                    raise RuntimeError("fault word set by the probe sort")
-                del probe
-            except Exception as exc:                      # noqa: BLE001 -- reported below, on every rank
-                why = f"{type(exc).__name__}: {exc}"
-            bad = torch.tensor([1 if why else 0], dtype=torch.int32, device="cuda")
-            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-            if int(bad.item()):
-                print(f"bench.py[rank {rank}]: C++ RCCL step unavailable ({why or 'failed on another rank'}); "
-                      f"using the torch.distributed driver", file=sys.stderr, flush=True)
-                if backend is not None:
-                    backend.close()
-                exchange_path = "torch"
-                backend = HipBackend(r)
-
-                def sharded(keys):
-                    return distributed_sort(keys, backend=backend, exchange_always=args.exercise_exchange, partition="msb")
-            else:
-                def sharded(keys):
-                    return backend.sort(keys)
-        else:
+        backend, why = None, ""
+        try:
+            backend = ShardedSorter(r, partition=args.partition)
+            probe = backend.sort(master[: min(n, 1 << 16)].clone())
+            torch.cuda.synchronize()
+            if backend.check_fault() != 0:
+                raise RuntimeError("fault word set by the probe sort")
+            del probe
+        except Exception as exc:                      # noqa: BLE001 -- reported below, on every rank
+            why = f"{type(exc).__name__}: {exc}"
+        bad = torch.tensor([1 if why else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            print(f"bench.py[rank {rank}]: C++ RCCL step unavailable ({why or 'failed on another rank'}); "
+                  f"using the torch.distributed driver", file=sys.stderr, flush=True)
+            if backend is not None:
+                backend.close()
             exchange_path = "torch"
-            # skewed keys: sampled splitters, the torch.distributed driver over the same kernels
             backend = HipBackend(r)
 
             def sharded(keys):
                 return distributed_sort(keys, backend=backend, exchange_always=args.exercise_exchange, partition=args.partition)
+        else:
+            def sharded(keys):
+                return backend.sort(keys)
 
         def run_step(kv):
             sharded(kv[0])
@@ -572,7 +565,7 @@ def main(argv=None):
         if distributed:
             total_txt = f"2^{(n * world).bit_length() - 1} keys over {world} GPU{'s' if world > 1 else ''}" if (n * world) & (n * world - 1) == 0 else f"{n * world} keys"
             workload = (f"{total_txt} = 2^{log2_keys} uniform uint32 keys per GPU (mt19937 seed=rank), "
-                        f"{'MSB-bucket' if args.partition == 'msb' else 'sampled-splitter'} partition + {'grouped ncclSend/ncclRecv (C++ step, lsdsort_sharded_u32_device)' if exchange_path == 'c++' else 'torch.distributed all-to-all'} over xGMI + "
+                        f"{'MSB-bucket' if args.partition == 'msb' else 'sampled-splitter'} partition + {'grouped ncclSend/ncclRecv (C++ step, lsdsort_sharded_u32_device_ex)' if exchange_path == 'c++' else 'torch.distributed all-to-all'} over xGMI + "
                         f"local {r}-bit LSD sort ({passes} passes) per step"
                         + (" [BASELINE configs[3]]" if n * world == 1 << 30 and world == 8 else ""))
         else:

@@ -214,6 +214,13 @@ LSDSORT_API int lsdsort_splitter_partition_u32_device(const uint32_t* d_in, uint
                                                       int log2_buckets, const uint32_t* splitters,
                                                       uint64_t* d_counts, void* d_workspace,
                                                       size_t workspace_bytes, void* hip_stream);
+/* The same with 64-bit thresholds (HOST array, 2^log2_buckets - 1 ascending values in [0, 2^32]):
+ * bucket(key) = number of thresholds <= key, and 2^32 stands for "above every key", which a 32-bit splitter
+ * cannot say.  The form the sharded step's splitter rule uses (lsdsort_sharded_thresholds). */
+LSDSORT_API int lsdsort_threshold_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size_t n,
+                                                       int log2_buckets, const uint64_t* thresholds,
+                                                       uint64_t* d_counts, void* d_workspace,
+                                                       size_t workspace_bytes, void* hip_stream);
 
 /* ---- multi-GPU sort over RCCL / xGMI (BASELINE.json configs[3]) ------------------------ */
 /* New work: the reference is single-GPU.  Rank b of `world` (1, 2, 4 or 8) ends up
@@ -249,16 +256,40 @@ LSDSORT_API int lsdsort_sharded_u32_device(lsdsort_comm* comm, const uint32_t* d
                                            uint64_t* global_offset, uint64_t* counts_matrix,
                                            void* d_workspace, size_t workspace_bytes, int radix_bits,
                                            void* hip_stream);
+/* The same step with the rule that decides which rank owns a key:
+ *   LSDSORT_PARTITION_MSB        the top log2(world) key bits, as above: no extra work, balanced for uniform keys;
+ *   LSDSORT_PARTITION_SPLITTERS  sampled splitters, for keys fixed MSB buckets would not balance.  Step 0 is added:
+ *      every rank samples LSDSORT_SPLITTER_SAMPLES of its keys at a regular stride, one ncclAllGather hands every
+ *      sample to every rank (a second, earlier host wait), and the sorted sample of (key, source rank) pairs is cut into
+ *      `world` equal parts (lsdsort_sharded_thresholds).  A splitter is such a PAIR: keys equal to a splitter's value go
+ *      below it from ranks before the splitter's rank and above it from the others, so a run of one value longer than a
+ *      bucket is still cut (between source ranks) and the exchange stays stable.  Rank b then owns the pairs between
+ *      splitters b-1 and b; the concatenation of the ranks' outputs is the sorted array as before (an MSB-style
+ *      "which rank owns key k" question has no single answer for a value that sits on a splitter). */
+#define LSDSORT_PARTITION_MSB 0
+#define LSDSORT_PARTITION_SPLITTERS 1
+#define LSDSORT_SPLITTER_SAMPLES 512
+LSDSORT_API int lsdsort_sharded_u32_device_ex(lsdsort_comm* comm, const uint32_t* d_keys_in, size_t n_local,
+                                              uint32_t* d_out, size_t out_capacity, size_t* n_out,
+                                              uint64_t* global_offset, uint64_t* counts_matrix,
+                                              void* d_workspace, size_t workspace_bytes, int radix_bits,
+                                              int partition, void* hip_stream);
+/* Host-side arithmetic of step 0, exported so that it can be checked without a GPU.  `gathered` is
+ * [world][1 + samples_per_rank] uint32: per source rank the number of valid samples, then the samples.
+ * thresholds[b-1] (b = 1 .. world-1, ascending, values in [0, 2^32]) is the smallest key of rank `rank` that goes to
+ * bucket b or higher: bucket(key) = number of thresholds <= key; 2^32 = no key of this rank does. */
+LSDSORT_API int lsdsort_sharded_thresholds(const uint32_t* gathered, int world, int samples_per_rank, int rank,
+                                           uint64_t* thresholds);
 /* After the stream has drained: the fault words of the step's two chained kernels sequences (partition pass, local
  * sort) in a workspace last used with these sizes; LSDSORT_OK or LSDSORT_ERR_DEVICE_FAULT.  Synchronises hip_stream. */
 LSDSORT_API int lsdsort_sharded_check_device(void* d_workspace, size_t n_local, size_t out_capacity, int world,
                                              int radix_bits, void* hip_stream);
+/* Text of the most recent failed RCCL call on this thread ("" if none). */
+LSDSORT_API const char* lsdsort_last_comm_error(void);
 /* Host-side arithmetic of step 3, exported so that it can be checked without a GPU: from the world x world
  * count matrix ([src][dst]) the element offsets of rank `rank`'s sends in its partitioned shard, of its
  * receives in its output (source-rank order keeps the exchange stable), its output size and global offset.
  * Returns LSDSORT_ERR_INVALID_ARG for a bad world / rank. */
-/* Text of the most recent failed RCCL call on this thread ("" if none). */
-LSDSORT_API const char* lsdsort_last_comm_error(void);
 LSDSORT_API int lsdsort_sharded_plan(const uint64_t* counts_matrix, int world, int rank, uint64_t* send_offsets,
                                      uint64_t* recv_offsets, uint64_t* n_out, uint64_t* global_offset);
 

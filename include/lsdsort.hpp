@@ -102,12 +102,15 @@ public:
         uint64_t global_offset;   // index of the first of them in the global order
     };
     // Collective.  d_keys_in is left untouched; the exchange and the local sort stay queued on hip_stream.
+    // partition: LSDSORT_PARTITION_MSB (top key bits; uniform keys) or LSDSORT_PARTITION_SPLITTERS (sampled; any keys).
     slice sort_device(const uint32_t* d_keys_in, size_t n_local, uint32_t* d_out, size_t out_capacity, void* d_workspace,
-                      size_t workspace_bytes_, int radix_bits = 8, void* hip_stream = nullptr, uint64_t* counts_matrix = nullptr)
+                      size_t workspace_bytes_, int radix_bits = 8, void* hip_stream = nullptr, uint64_t* counts_matrix = nullptr,
+                      int partition = LSDSORT_PARTITION_MSB)
     {
         slice s{0, 0};
-        check(lsdsort_sharded_u32_device(c_, d_keys_in, n_local, d_out, out_capacity, &s.n, &s.global_offset, counts_matrix,
-                                         d_workspace, workspace_bytes_, radix_bits, hip_stream), "lsdsort_sharded_u32_device");
+        check(lsdsort_sharded_u32_device_ex(c_, d_keys_in, n_local, d_out, out_capacity, &s.n, &s.global_offset, counts_matrix,
+                                            d_workspace, workspace_bytes_, radix_bits, partition, hip_stream),
+              "lsdsort_sharded_u32_device_ex");
         return s;
     }
 

@@ -66,6 +66,8 @@ SIGNATURES = {
                                                  c_size, ctypes.c_void_p]),
     "lsdsort_splitter_partition_u32_device": (c_int, [c_u32p, c_u32p, c_size, c_int, ctypes.POINTER(ctypes.c_uint32),
                                                       ctypes.c_void_p, ctypes.c_void_p, c_size, ctypes.c_void_p]),
+    "lsdsort_threshold_partition_u32_device": (c_int, [c_u32p, c_u32p, c_size, c_int, ctypes.POINTER(ctypes.c_uint64),
+                                                       ctypes.c_void_p, ctypes.c_void_p, c_size, ctypes.c_void_p]),
     "lsdsort_comm_unique_id": (c_int, [ctypes.c_void_p]),
     "lsdsort_comm_create": (c_int, [ctypes.c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "lsdsort_comm_destroy": (c_int, [ctypes.c_void_p]),
@@ -75,6 +77,10 @@ SIGNATURES = {
     "lsdsort_sharded_u32_device": (c_int, [ctypes.c_void_p, c_u32p, c_size, c_u32p, c_size, ctypes.POINTER(c_size),
                                            ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p,
                                            c_size, c_int, ctypes.c_void_p]),
+    "lsdsort_sharded_u32_device_ex": (c_int, [ctypes.c_void_p, c_u32p, c_size, c_u32p, c_size, ctypes.POINTER(c_size),
+                                              ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p,
+                                              c_size, c_int, c_int, ctypes.c_void_p]),
+    "lsdsort_sharded_thresholds": (c_int, [ctypes.POINTER(ctypes.c_uint32), c_int, c_int, c_int, ctypes.POINTER(ctypes.c_uint64)]),
     "lsdsort_sharded_check_device": (c_int, [ctypes.c_void_p, c_size, c_size, c_int, c_int, ctypes.c_void_p]),
     "lsdsort_sharded_plan": (c_int, [ctypes.POINTER(ctypes.c_uint64), c_int, c_int, ctypes.POINTER(ctypes.c_uint64),
                                      ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),

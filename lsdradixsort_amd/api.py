@@ -310,6 +310,43 @@ def MSBPartition(d_keys, msb_bits: int, stream=None):
     return out, counts
 
 
+def ThresholdPartition(d_keys, thresholds, stream=None):
+    """Stable partition by 64-bit thresholds (1, 3 or 7 ascending values in [0, 2^32]; 2^32 = above every key):
+    bucket(key) = number of thresholds <= key -> (partitioned keys, int64 bucket counts).  The form the sharded step's
+    splitter rule uses (``lsdsort_threshold_partition_u32_device``)."""
+    torch = _torch()
+    _dev_i32(d_keys, "d_keys")
+    th = [int(x) for x in thresholds]
+    if len(th) not in (0, 1, 3, 7):
+        raise ValueError("threshold count must be 0, 1, 3 or 7 (2, 4 or 8 buckets)")
+    bits = (len(th) + 1).bit_length() - 1
+    n = d_keys.numel()
+    out = torch.empty_like(d_keys)
+    counts = torch.zeros(1 << bits, dtype=torch.int64, device=d_keys.device)
+    ws = torch.empty(max(int(lib().lsdsort_msb_partition_workspace_bytes(n, bits)), 256), dtype=torch.uint8,
+                     device=d_keys.device)
+    arr = (ctypes.c_uint64 * max(len(th), 1))(*th)
+    check(lib().lsdsort_threshold_partition_u32_device(d_keys.data_ptr(), out.data_ptr(), n, bits, arr, counts.data_ptr(),
+                                                       ws.data_ptr(), ws.numel(), _stream(stream)),
+          "lsdsort_threshold_partition_u32_device")
+    if n:
+        check(lib().lsdsort_check_device(ws.data_ptr(), _stream(stream)), "lsdsort_check_device")
+    return out, counts
+
+
+def sharded_thresholds(gathered, world: int, samples_per_rank: int, rank: int):
+    """Host arithmetic of the sharded step's splitter rule (``lsdsort_sharded_thresholds``; no GPU): ``gathered`` is a
+    [world][1 + samples_per_rank] uint32 array (valid count, then samples, per source rank) -> world - 1 thresholds
+    of rank ``rank`` (Python ints in [0, 2^32])."""
+    import numpy as np
+
+    g = np.ascontiguousarray(gathered, dtype=np.uint32).reshape(world, 1 + samples_per_rank)
+    out = (ctypes.c_uint64 * max(world - 1, 1))()
+    check(lib().lsdsort_sharded_thresholds(g.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), world, samples_per_rank, rank, out),
+          "lsdsort_sharded_thresholds")
+    return [int(out[i]) for i in range(world - 1)]
+
+
 def SplitterPartition(d_keys, splitters, stream=None):
     """Stable partition by value: bucket(key) = number of ``splitters`` (ascending uint32 values, 1, 3 or 7 of
     them) <= key -> (partitioned keys, int64 bucket counts).  No splitters: one bucket."""

@@ -119,7 +119,8 @@ static hipError_t launch_digit_histograms_inst(uint32_t shift0, const uint32_t* 
 // replicated LDS counters per bucket.
 // ------------------------------------------------------------------------------------------
 struct SplitterSet {
-    uint32_t count;
+    uint32_t count;   // buckets - 1
+    uint32_t live;    // splitters compared (the rest lie above every key)
     uint32_t value[7];
 };
 
@@ -135,7 +136,7 @@ __global__ void __launch_bounds__(kHistThreads) bucket_histogram_kernel(const ui
     auto count_key = [&](uint32_t k) {
         uint32_t b = 0;
 #pragma unroll
-        for (int i = 0; i < 7; i++) b += (i < (int)sp.count && k >= sp.value[i]) ? 1u : 0u;
+        for (int i = 0; i < 7; i++) b += (i < (int)sp.live && k >= sp.value[i]) ? 1u : 0u;
         atomicAdd(&s_hist[b * C + (tid & (C - 1))], 1u);
     };
     const uint4* __restrict__ keys4 = reinterpret_cast<const uint4*>(keys);
@@ -158,13 +159,14 @@ __global__ void __launch_bounds__(kHistThreads) bucket_histogram_kernel(const ui
     }
 }
 
-hipError_t launch_bucket_histogram(int bits, const uint32_t* splitters_host, const uint32_t* keys, uint32_t n,
+hipError_t launch_bucket_histogram(int bits, const uint32_t* splitters_host, int live, const uint32_t* keys, uint32_t n,
                                    uint32_t* hist, hipStream_t stream)
 {
-    if (bits < 1 || bits > 3 || !splitters_host) return hipErrorInvalidValue;
+    if (bits < 1 || bits > 3 || !splitters_host || live < 0 || live > (1 << bits) - 1) return hipErrorInvalidValue;
     SplitterSet sp{};
     sp.count = (1u << bits) - 1u;
-    for (uint32_t i = 0; i < sp.count; i++) sp.value[i] = splitters_host[i];
+    sp.live = (uint32_t)live;
+    for (uint32_t i = 0; i < sp.live; i++) sp.value[i] = splitters_host[i];
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const uint32_t vec_chunks = aligned ? n / (kHistThreads * 4) : 0;
     uint32_t blocks = aligned ? vec_chunks : (n + kHistThreads * 16 - 1) / (kHistThreads * 16);
@@ -857,6 +859,24 @@ __global__ void store_u64_kernel(uint64_t* out, uint64_t value) { *out = value; 
 hipError_t launch_store_u64(uint64_t* out, uint64_t value, hipStream_t stream)
 {
     hipLaunchKernelGGL(store_u64_kernel, dim3(1), dim3(1), 0, stream, out, value);
+    return hipGetLastError();
+}
+
+// A regular sample of a shard for the splitter choice (sharded.hip): out[0] = m = min(samples, n),
+// out[1 + i] = keys[i * n / m] for i < m; the slots behind stay as they are.
+__global__ void __launch_bounds__(256) sample_keys_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t samples,
+                                                          uint32_t* __restrict__ out)
+{
+    const uint32_t m = n < samples ? n : samples;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) out[0] = m;
+    if (i < m) out[1 + i] = keys[(size_t)(((uint64_t)i * n) / m)];
+}
+
+hipError_t launch_sample_keys(const uint32_t* keys, uint32_t n, uint32_t samples, uint32_t* out, hipStream_t stream)
+{
+    if (samples == 0 || !out || (n && !keys)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sample_keys_kernel, dim3((samples + 255) / 256), dim3(256), 0, stream, keys, n, samples, out);
     return hipGetLastError();
 }
 

@@ -105,8 +105,11 @@ struct PassParams {
     unsigned long long* stats;   // diagnostic builds only (LSD_PHASE_STATS); null otherwise
     // Splitter partition (narrow-digit kernels only, multi-GPU step 1 for skewed keys): when
     // num_splitters != 0 it is 2^R - 1 and the "digit" of a key is its bucket, the number of
-    // splitters <= key (ascending splitters); shift is ignored.
+    // splitters <= key (ascending splitters); shift is ignored.  Only the first live_splitters are
+    // compared: the rest stand for thresholds above every key (a splitter (0xFFFFFFFF, rank q) seen from
+    // a rank below q, sharded.hip), which no 32-bit value can express.
     uint32_t num_splitters;
+    uint32_t live_splitters;
     uint32_t splitters[7];
     KeyTransform xin;    // first pass: applied to every key as it is loaded
     KeyTransform xout;   // last pass: undone on every key as it is stored
@@ -129,8 +132,8 @@ hipError_t probe_lds_add_lane_order(bool* ok, hipStream_t stream);
 
 // Stage 1, onesweep: all `groups` digit histograms (digit g at bit shift0 + g*radix_bits) in
 // one read; hist[g][d] must be zero on entry.
-// counts[b] += keys whose bucket (number of ascending splitters <= key) is b; 2^bits buckets, bits <= 3
-hipError_t launch_bucket_histogram(int bits, const uint32_t* splitters_host, const uint32_t* keys, uint32_t n,
+// counts[b] += keys whose bucket (number of the first `live` ascending splitters <= key) is b; 2^bits buckets, bits <= 3
+hipError_t launch_bucket_histogram(int bits, const uint32_t* splitters_host, int live, const uint32_t* keys, uint32_t n,
                                    uint32_t* hist, hipStream_t stream);
 hipError_t launch_digit_histograms(int radix_bits, int groups, uint32_t shift0, const uint32_t* keys,
                                    uint32_t n, uint32_t* hist, hipStream_t stream);
@@ -169,5 +172,8 @@ hipError_t launch_widen_counts(const uint32_t* hist32, uint64_t* counts64, int b
 
 // *out = value (stream-ordered).
 hipError_t launch_store_u64(uint64_t* out, uint64_t value, hipStream_t stream);
+
+// out[0] = m = min(samples, n); out[1 + i] = keys[i * n / m], i < m (the splitter choice's sample of a shard).
+hipError_t launch_sample_keys(const uint32_t* keys, uint32_t n, uint32_t samples, uint32_t* out, hipStream_t stream);
 
 }  // namespace lsd

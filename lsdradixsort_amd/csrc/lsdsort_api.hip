@@ -877,14 +877,17 @@ size_t lsdsort_msb_partition_workspace_bytes(size_t n, int msb_bits)
 }
 
 // Stable partition into 2^msb_bits buckets: by the top msb_bits key bits (splitters == nullptr) or by
-// 2^msb_bits - 1 ascending splitters (bucket = number of splitters <= key).
+// 2^msb_bits - 1 ascending splitters (bucket = number of splitters <= key), of which the first `live` are
+// given (live < 0: all of them); the others lie above every key.
 static int partition_impl(const uint32_t* d_in, uint32_t* d_out, size_t n, int msb_bits, const uint32_t* splitters,
                           uint64_t* d_counts, void* d_workspace, size_t workspace_bytes, void* hip_stream,
-                          hipEvent_t counts_ready = nullptr)
+                          hipEvent_t counts_ready = nullptr, int live = -1)
 {
     if (msb_bits < 0 || msb_bits > 3 || !d_counts) return LSDSORT_ERR_INVALID_ARG;
+    if (live < 0) live = (1 << msb_bits) - 1;
+    if (live > (1 << msb_bits) - 1) return LSDSORT_ERR_INVALID_ARG;
     if (splitters)
-        for (int i = 1; i < (1 << msb_bits) - 1; i++)
+        for (int i = 1; i < live; i++)
             if (splitters[i] < splitters[i - 1]) return LSDSORT_ERR_INVALID_ARG;
     if (n > LSDSORT_MAX_KEYS) return LSDSORT_ERR_TOO_LARGE;
     if (n > 0 && (!d_in || !d_out || d_in == d_out)) return LSDSORT_ERR_INVALID_ARG;
@@ -911,7 +914,7 @@ static int partition_impl(const uint32_t* d_in, uint32_t* d_out, size_t n, int m
         const uint32_t shift = (uint32_t)(32 - msb_bits);
         const TileShape* shape = current_shape(msb_bits, false, n, LSDSORT_ALGO_ONESWEEP);
         if (splitters)
-            LSD_HIP(lsd::launch_bucket_histogram(msb_bits, splitters, d_in, (uint32_t)n, hist, stream));
+            LSD_HIP(lsd::launch_bucket_histogram(msb_bits, splitters, live, d_in, (uint32_t)n, hist, stream));
         else
             LSD_HIP(lsd::launch_digit_histograms(msb_bits, 1, shift, d_in, (uint32_t)n, hist, stream));
         LSD_HIP(lsd::launch_scan_regions(msb_bits, 1, 1, hist, (uint32_t)n, (uint32_t)shape->tile(), 0, table, stream));
@@ -933,7 +936,8 @@ static int partition_impl(const uint32_t* d_in, uint32_t* d_out, size_t n, int m
         p.spin_limit = g_spin_limit.load(std::memory_order_relaxed);
         if (splitters) {
             p.num_splitters = (1u << msb_bits) - 1u;
-            for (uint32_t i = 0; i < p.num_splitters; i++) p.splitters[i] = splitters[i];
+            p.live_splitters = (uint32_t)live;
+            for (uint32_t i = 0; i < p.live_splitters; i++) p.splitters[i] = splitters[i];
         }
         LSD_HIP(lsd::launch_rank_scatter(msb_bits, *shape, resolve_rank_method(dev, msb_bits), true, p, stream));
     } else {
@@ -951,6 +955,24 @@ int partition_with_event(const uint32_t* d_in, uint32_t* d_out, size_t n, int ms
 {
     return partition_impl(d_in, d_out, n, msb_bits, nullptr, d_counts, d_workspace, workspace_bytes, stream, counts_ready);
 }
+// the same by thresholds: bucket of a key = number of thresholds <= key; ascending values in [0, 2^32], 2^32 = above every key
+int threshold_partition_with_event(const uint32_t* d_in, uint32_t* d_out, size_t n, int log2_buckets, const uint64_t* thresholds,
+                                   uint64_t* d_counts, void* d_workspace, size_t workspace_bytes, hipStream_t stream,
+                                   hipEvent_t counts_ready)
+{
+    if (log2_buckets < 0 || log2_buckets > 3) return LSDSORT_ERR_INVALID_ARG;
+    if (log2_buckets == 0)
+        return partition_impl(d_in, d_out, n, 0, nullptr, d_counts, d_workspace, workspace_bytes, stream, counts_ready);
+    if (!thresholds) return LSDSORT_ERR_INVALID_ARG;
+    uint32_t values[7] = {};
+    int live = 0;
+    const int count = (1 << log2_buckets) - 1;
+    for (int i = 0; i < count; i++) {
+        if (thresholds[i] > (1ull << 32) || (i > 0 && thresholds[i] < thresholds[i - 1])) return LSDSORT_ERR_INVALID_ARG;
+        if (thresholds[i] < (1ull << 32)) values[live++] = (uint32_t)thresholds[i];
+    }
+    return partition_impl(d_in, d_out, n, log2_buckets, values, d_counts, d_workspace, workspace_bytes, stream, counts_ready, live);
+}
 }  // namespace lsd
 extern "C" {
 
@@ -967,6 +989,14 @@ int lsdsort_splitter_partition_u32_device(const uint32_t* d_in, uint32_t* d_out,
     if (log2_buckets > 0 && !splitters) return LSDSORT_ERR_INVALID_ARG;
     return partition_impl(d_in, d_out, n, log2_buckets, log2_buckets > 0 ? splitters : nullptr, d_counts, d_workspace,
                           workspace_bytes, hip_stream);
+}
+
+int lsdsort_threshold_partition_u32_device(const uint32_t* d_in, uint32_t* d_out, size_t n, int log2_buckets,
+                                           const uint64_t* thresholds, uint64_t* d_counts, void* d_workspace,
+                                           size_t workspace_bytes, void* hip_stream)
+{
+    return lsd::threshold_partition_with_event(d_in, d_out, n, log2_buckets, thresholds, d_counts, d_workspace, workspace_bytes,
+                                               static_cast<hipStream_t>(hip_stream), nullptr);
 }
 
 }  // extern "C"

@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             if (p.num_splitters) {   // uniform across the grid
                 uint32_t b = 0;
 #pragma unroll
-                for (int i = 0; i < (1 << R) - 1; i++) b += k >= p.splitters[i] ? 1u : 0u;
+                for (int i = 0; i < (1 << R) - 1; i++) b += ((uint32_t)i < p.live_splitters && k >= p.splitters[i]) ? 1u : 0u;
                 return b;
             }
         }

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -34,6 +35,9 @@ namespace lsd {
 // lsdsort_api.hip
 int partition_with_event(const uint32_t* d_in, uint32_t* d_out, size_t n, int msb_bits, uint64_t* d_counts,
                          void* d_workspace, size_t workspace_bytes, hipStream_t stream, hipEvent_t counts_ready);
+int threshold_partition_with_event(const uint32_t* d_in, uint32_t* d_out, size_t n, int log2_buckets, const uint64_t* thresholds,
+                                   uint64_t* d_counts, void* d_workspace, size_t workspace_bytes, hipStream_t stream,
+                                   hipEvent_t counts_ready);
 void set_last_hip_error(hipError_t e);
 }  // namespace lsd
 
@@ -132,6 +136,8 @@ struct ShardedLayout {
     size_t part_ws = 0;    // workspace of the partition pass
     size_t send = 0;       // the partitioned shard: bucket 0 | bucket 1 | ...
     size_t sort_ws = 0;    // workspace of the local sort
+    size_t samp = 0;       // u32[1 + S]: this rank's sample (count, then keys) for the splitter rule
+    size_t samp_all = 0;   // u32[W][1 + S]: everybody's
     size_t total = 0;
     size_t part_ws_bytes = 0, sort_ws_bytes = 0;
 };
@@ -153,6 +159,10 @@ ShardedLayout make_sharded_layout(size_t n_local_max, size_t out_capacity, int w
     L.sort_ws = off;
     L.sort_ws_bytes = lsdsort_workspace_bytes(out_capacity, radix_bits, 0);
     off = align_up(off + L.sort_ws_bytes);
+    L.samp = off;
+    off = align_up(off + (size_t)(1 + LSDSORT_SPLITTER_SAMPLES) * sizeof(uint32_t));
+    L.samp_all = off;
+    off = align_up(off + (size_t)world * (1 + LSDSORT_SPLITTER_SAMPLES) * sizeof(uint32_t));
     L.total = off;
     return L;
 }
@@ -164,7 +174,9 @@ struct lsdsort_comm {
     int world = 1, rank = 0, device = 0;
     hipStream_t side = nullptr;
     hipEvent_t counts_ready = nullptr;
-    uint64_t* h_all = nullptr;   // pinned: [W][W + 1]
+    hipEvent_t sample_ready = nullptr;
+    uint64_t* h_all = nullptr;       // pinned: [W][W + 1]
+    uint32_t* h_samples = nullptr;   // pinned: [W][1 + S]
 };
 
 namespace {
@@ -174,7 +186,10 @@ int finish_comm(lsdsort_comm* c)
     SH_HIP(hipGetDevice(&c->device));
     SH_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     SH_HIP(hipEventCreateWithFlags(&c->counts_ready, hipEventDisableTiming));
+    SH_HIP(hipEventCreateWithFlags(&c->sample_ready, hipEventDisableTiming));
     SH_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_all), (size_t)c->world * (c->world + 1) * sizeof(uint64_t), hipHostMallocDefault));
+    SH_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_samples), (size_t)c->world * (1 + LSDSORT_SPLITTER_SAMPLES) * sizeof(uint32_t),
+                         hipHostMallocDefault));
     return LSDSORT_OK;
 }
 
@@ -227,7 +242,9 @@ int lsdsort_comm_destroy(lsdsort_comm* c)
     int prev = 0;
     const bool switched = hipGetDevice(&prev) == hipSuccess && prev != c->device && hipSetDevice(c->device) == hipSuccess;
     if (c->h_all) (void)hipHostFree(c->h_all);
+    if (c->h_samples) (void)hipHostFree(c->h_samples);
     if (c->counts_ready) (void)hipEventDestroy(c->counts_ready);
+    if (c->sample_ready) (void)hipEventDestroy(c->sample_ready);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
     if (switched) (void)hipSetDevice(prev);
@@ -264,11 +281,49 @@ int lsdsort_sharded_plan(const uint64_t* m, int world, int rank, uint64_t* send_
     return LSDSORT_OK;
 }
 
+int lsdsort_sharded_thresholds(const uint32_t* gathered, int world, int samples_per_rank, int rank, uint64_t* thresholds)
+{
+    if (!gathered || log2_world(world) < 0 || samples_per_rank < 1 || rank < 0 || rank >= world || (world > 1 && !thresholds))
+        return LSDSORT_ERR_INVALID_ARG;
+    // every sampled key as (key, source rank): equal keys are told apart by where they came from, so a run of one
+    // value longer than a bucket can still be cut (between ranks), and the cut keeps the exchange stable
+    std::vector<uint64_t> tuples;
+    tuples.reserve((size_t)world * samples_per_rank);
+    for (int src = 0; src < world; src++) {
+        const uint32_t* row = gathered + (size_t)src * (1 + samples_per_rank);
+        if (row[0] > (uint32_t)samples_per_rank) return LSDSORT_ERR_INVALID_ARG;
+        for (uint32_t i = 0; i < row[0]; i++) tuples.push_back(((uint64_t)row[1 + i] << 8) | (uint64_t)src);
+    }
+    std::sort(tuples.begin(), tuples.end());
+    const size_t total = tuples.size();
+    for (int b = 1; b < world; b++) {
+        if (total == 0) {   // nothing to sort anywhere: any rule does
+            thresholds[b - 1] = 1ull << 32;
+            continue;
+        }
+        const uint64_t cut = tuples[(size_t)(((unsigned __int128)b * total) / world)];
+        const uint64_t key = cut >> 8;
+        const int from = (int)(cut & 0xFF);
+        // (k, rank) >= (key, from)  <=>  k > key, or k == key and rank >= from  <=>  k >= key + (rank < from)
+        thresholds[b - 1] = key + (rank < from ? 1u : 0u);
+    }
+    return LSDSORT_OK;
+}
+
 int lsdsort_sharded_u32_device(lsdsort_comm* c, const uint32_t* d_keys_in, size_t n_local, uint32_t* d_out,
                                size_t out_capacity, size_t* n_out, uint64_t* global_offset, uint64_t* counts_matrix,
                                void* d_workspace, size_t workspace_bytes, int radix_bits, void* hip_stream)
 {
+    return lsdsort_sharded_u32_device_ex(c, d_keys_in, n_local, d_out, out_capacity, n_out, global_offset, counts_matrix, d_workspace,
+                                         workspace_bytes, radix_bits, LSDSORT_PARTITION_MSB, hip_stream);
+}
+
+int lsdsort_sharded_u32_device_ex(lsdsort_comm* c, const uint32_t* d_keys_in, size_t n_local, uint32_t* d_out,
+                                  size_t out_capacity, size_t* n_out, uint64_t* global_offset, uint64_t* counts_matrix,
+                                  void* d_workspace, size_t workspace_bytes, int radix_bits, int partition, void* hip_stream)
+{
     if (!c || !n_out || !global_offset) return LSDSORT_ERR_INVALID_ARG;
+    if (partition != LSDSORT_PARTITION_MSB && partition != LSDSORT_PARTITION_SPLITTERS) return LSDSORT_ERR_INVALID_ARG;
     if (n_local > LSDSORT_MAX_KEYS || out_capacity > LSDSORT_MAX_KEYS) return LSDSORT_ERR_TOO_LARGE;
     if ((n_local > 0 && !d_keys_in) || (out_capacity > 0 && !d_out)) return LSDSORT_ERR_INVALID_ARG;
     if (lsdsort_workspace_bytes(1, radix_bits, 0) == 0) return LSDSORT_ERR_INVALID_ARG;
@@ -285,8 +340,28 @@ int lsdsort_sharded_u32_device(lsdsort_comm* c, const uint32_t* d_keys_in, size_
     uint32_t* d_send = reinterpret_cast<uint32_t*>(ws + L.send);
     Rccl& R = rccl();
 
+    // 0.  splitter rule only: a regular sample of every shard to every rank (one more host wait, ahead of the partition);
+    //     each rank then cuts the sorted (key, source rank) sample into W equal parts and derives ITS thresholds
+    uint64_t thresholds[8] = {};
+    if (partition == LSDSORT_PARTITION_SPLITTERS) {
+        constexpr int S = LSDSORT_SPLITTER_SAMPLES;
+        uint32_t* d_samp = reinterpret_cast<uint32_t*>(ws + L.samp);
+        uint32_t* d_samp_all = reinterpret_cast<uint32_t*>(ws + L.samp_all);
+        SH_HIP(lsd::launch_sample_keys(d_keys_in, (uint32_t)n_local, (uint32_t)S, d_samp, stream));
+        SH_HIP(hipEventRecord(c->sample_ready, stream));
+        SH_HIP(hipStreamWaitEvent(c->side, c->sample_ready, 0));
+        SH_NCCL(R.AllGather(d_samp, d_samp_all, (size_t)(1 + S), ncclUint32, c->comm, c->side));
+        SH_HIP(hipMemcpyAsync(c->h_samples, d_samp_all, (size_t)W * (1 + S) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->side));
+        SH_HIP(hipStreamSynchronize(c->side));
+        SH_TRY(lsdsort_sharded_thresholds(c->h_samples, W, S, c->rank, thresholds));
+    }
+
     // 1 + 2.  main stream: counts, EVENT, partition pass.  side stream: count exchange while the partition runs.
-    SH_TRY(lsd::partition_with_event(d_keys_in, d_send, n_local, bits, d_vec, ws + L.part_ws, L.part_ws_bytes, stream, c->counts_ready));
+    if (partition == LSDSORT_PARTITION_SPLITTERS)
+        SH_TRY(lsd::threshold_partition_with_event(d_keys_in, d_send, n_local, bits, thresholds, d_vec, ws + L.part_ws, L.part_ws_bytes,
+                                                   stream, c->counts_ready));
+    else
+        SH_TRY(lsd::partition_with_event(d_keys_in, d_send, n_local, bits, d_vec, ws + L.part_ws, L.part_ws_bytes, stream, c->counts_ready));
     SH_HIP(hipStreamWaitEvent(c->side, c->counts_ready, 0));
     SH_HIP(lsd::launch_store_u64(d_vec + W, (uint64_t)out_capacity, c->side));
     SH_NCCL(R.AllGather(d_vec, d_all, (size_t)(W + 1), ncclUint64, c->comm, c->side));

@@ -83,12 +83,15 @@ class ShardResult:
 
 
 class ShardedSorter:
-    """One rank of the multi-GPU sort through the C++ step (MSB buckets).  Collective construction: rank 0 makes
+    """One rank of the multi-GPU sort through the C++ step (``partition``: "msb" buckets, or "splitters" sampled
+    and cut inside the step for keys MSB buckets would not balance).  Collective construction: rank 0 makes
     the RCCL id, ``torch.distributed`` (any backend) broadcasts its 128 bytes, every rank creates its communicator
     on its current CUDA/HIP device.  Without an initialised process group it is a world of one (the RCCL calls
     are still made: a one-GPU box rehearses the whole path)."""
 
-    def __init__(self, radix_bits: int = 8, group=None, slack: float = 0.25):
+    PARTITIONS = {"msb": 0, "splitters": 1}     # LSDSORT_PARTITION_MSB / LSDSORT_PARTITION_SPLITTERS
+
+    def __init__(self, radix_bits: int = 8, group=None, slack: float = 0.25, partition: str = "msb"):
         import ctypes
 
         import torch
@@ -98,6 +101,9 @@ class ShardedSorter:
         from .errors import check
 
         self._api, self._ctypes, self._check = api, ctypes, check
+        if partition not in self.PARTITIONS:
+            raise ValueError(f"partition must be 'msb' or 'splitters', got {partition!r}")
+        self.partition = partition
         self.radix_bits = radix_bits
         self.slack = slack
         self.group = group
@@ -160,8 +166,9 @@ class ShardedSorter:
             n_out = ctypes.c_size_t(0)
             offset = ctypes.c_uint64(0)
             matrix = (ctypes.c_uint64 * (self.world * self.world))()
-            st = L.lsdsort_sharded_u32_device(self._comm, local_keys.data_ptr(), n_local, out.data_ptr(), cap, ctypes.byref(n_out),
-                                              ctypes.byref(offset), matrix, ws.data_ptr(), ws.numel(), self.radix_bits, stream)
+            st = L.lsdsort_sharded_u32_device_ex(self._comm, local_keys.data_ptr(), n_local, out.data_ptr(), cap, ctypes.byref(n_out),
+                                                 ctypes.byref(offset), matrix, ws.data_ptr(), ws.numel(), self.radix_bits,
+                                                 self.PARTITIONS[self.partition], stream)
             if st == -5 and attempt == 0:            # LSDSORT_ERR_TOO_LARGE on EVERY rank (skewed keys): exact sizes this time
                 cap = max(int(n_out.value), 1)
                 continue

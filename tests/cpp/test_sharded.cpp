@@ -38,7 +38,9 @@ int main()
         HIP_OK(hipStreamCreate(&stream));
         for (int rep = 0; rep < 3; rep++) {                 // the communicator and the workspace serve every step
             uint64_t matrix[1] = {0};
-            const auto s = comm.sort_device(d_in, n, d_out, cap, d_ws, ws_bytes, 8, stream, matrix);
+            // the last repetition takes the sampled-splitter rule (one more gather and host wait; no thresholds for one rank)
+            const auto s = comm.sort_device(d_in, n, d_out, cap, d_ws, ws_bytes, 8, stream, matrix,
+                                            rep == 2 ? LSDSORT_PARTITION_SPLITTERS : LSDSORT_PARTITION_MSB);
             HIP_OK(hipStreamSynchronize(stream));
             if (s.n != n || s.global_offset != 0 || matrix[0] != n) { std::fprintf(stderr, "slice %zu at %llu, matrix %llu\n", s.n, (unsigned long long)s.global_offset, (unsigned long long)matrix[0]); return 1; }
             std::vector<uint32_t> got(n), in_after(n);

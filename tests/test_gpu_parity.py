@@ -549,6 +549,64 @@ def test_splitter_partition(gpu, oracle_mod, nsplit):
         gpu.SplitterPartition(gpu.to_device(keys), [5, 4, 9])        # not ascending
 
 
+@pytest.mark.parametrize("nthr", [1, 3, 7])
+def test_threshold_partition(gpu, oracle_mod, nthr):
+    """The form of the partition the C++ step's splitter rule uses: 64-bit thresholds, 2^32 = above every key (a 32-bit
+    splitter cannot say that), 0 = below every key; keys equal to 0xFFFFFFFF and to thresholds; against numpy."""
+    rng = np.random.default_rng(50 + nthr)
+    for case, (n, seed) in enumerate(((3, 1), (4097, 2), ((1 << 20) + 7, 3), ((1 << 22) + 1001, 4))):
+        keys = oracle_mod.mt19937_keys(n, seed)
+        keys[rng.integers(0, n, size=max(1, n // 8))] = 0xFFFFFFFF
+        th = sorted(int(x) for x in rng.choice(keys, size=nthr, replace=True))
+        if case == 1:
+            th[-1] = 1 << 32                                          # the last bucket stays empty, 0xFFFFFFFF keys included
+            if nthr >= 3:
+                th[-2] = 1 << 32
+                th[0] = 0                                             # and the first one too
+        if case == 2:
+            th = [1 << 32] * nthr                                     # one bucket holds everything
+        if case == 3:
+            th[-1] = 0xFFFFFFFF                                       # the all-ones keys alone in the last bucket
+        out, counts = gpu.ThresholdPartition(gpu.to_device(keys), th)
+        bucket = np.zeros(n, dtype=np.int64)
+        for t in th:
+            if t < (1 << 32):
+                bucket += keys >= np.uint32(t)
+        order = np.argsort(bucket, kind="stable")
+        assert np.array_equal(counts.cpu().numpy(), np.bincount(bucket, minlength=nthr + 1)), (nthr, n, th)
+        assert np.array_equal(gpu.to_host(out), keys[order]), (nthr, n, th)
+    if nthr >= 3:
+        with pytest.raises(Exception):
+            gpu.ThresholdPartition(gpu.to_device(keys), [9, 4, 9] + [9] * (nthr - 3))                             # not ascending
+    with pytest.raises(Exception):
+        gpu.ThresholdPartition(gpu.to_device(keys), [(1 << 32) + 1] * nthr)                                       # out of range
+
+
+def test_cpp_sharded_step_splitter_rule_world_of_one(gpu, oracle_mod):
+    """lsdsort_sharded_u32_device_ex with LSDSORT_PARTITION_SPLITTERS as a world of one: the sample kernel, its
+    ncclAllGather and host wait, the threshold arithmetic (no thresholds for one rank) and the rest of the step, on
+    skewed, constant, tiny and empty shards."""
+    import torch
+    from lsdradixsort_amd.dist import ShardedSorter
+
+    sorter = ShardedSorter(8, partition="splitters")
+    try:
+        for n, seed in (((1 << 20) + 3, 5), (1, 7), (0, 8), (300, 9), ((1 << 22) + 77, 10)):
+            keys = oracle_mod.mt19937_keys(n, seed)
+            if seed == 5:
+                keys = (keys >> np.uint32(12)).astype(np.uint32)      # top bits clear
+            if seed == 10:
+                keys[:] = 0xFFFFFFFF
+            d = gpu.to_device(keys)
+            res = sorter.sort(d)
+            torch.cuda.synchronize()
+            assert res.global_offset == 0 and res.keys.numel() == n
+            assert np.array_equal(gpu.to_host(res.keys), np.sort(keys)), n
+            assert sorter.check_fault() == 0
+    finally:
+        sorter.close()
+
+
 # ----------------------------------------------------------------------------- other key types and orders (SURVEY 8f.4)
 @pytest.mark.parametrize("r", [8, 4])
 @pytest.mark.parametrize("descending", [False, True])
