@@ -560,6 +560,13 @@ def main(argv=None):
                         "config1_2p20_lsd_r8_mkeys_s": round(small.size / (t_small_lsd * 1e-3) / 1e6, 2),
                         "config1_note": "BASELINE configs[0]: 2^20 keys, std::sort and the restated CPU LSD, 1 thread, best of 3",
                         "host_cpus": os.cpu_count()}
+        if oracle.ref_available():
+            # the reference's own LSDRadixSort, compiled where it lies by oracle/Makefile (`make ref`) and carried along as
+            # oracle/_ref/libref_lsd.so: beside the restatement it checks, on the same sample
+            t_ref = oracle.time_ref_lsd_sort(sample, 8)
+            cpu_baseline["reference_lsd_r8_mkeys_s"] = round(m / (t_ref * 1e-3) / 1e6, 2)
+            cpu_baseline["reference_lsd_r8_note"] = ("kind 'reference': LSDRadixSort (LSDRadixSort.cu:62-69) itself, compiled from the "
+                                                     "reference tree into oracle/_ref, r=8, same sample, 1 thread")
 
     if rank == 0:
         if distributed:

@@ -262,6 +262,21 @@ def time_lsd_sort(keys, r: int = 8) -> float:
 
 
 # ----------------------------------------------------------------------------- the real reference
+def time_ref_lsd_sort(keys, r: int = 8) -> float:
+    """Milliseconds the reference's own compiled LSDRadixSort (.cu:62-69, oracle/_ref) takes on ``keys`` (buffers
+    prepared outside the timed call, as for the restatement)."""
+    import time
+
+    a = _u32(keys).copy()
+    b = np.empty_like(a)
+    b.fill(0)                                   # pages touched outside the timed call
+    h = np.zeros(1 << r, dtype=np.uint32)
+    R = ref()
+    t0 = time.perf_counter()
+    R.ref_lsd_sort(_p(a), _p(b), a.size, _p(h), r)
+    return (time.perf_counter() - t0) * 1e3
+
+
 def ref_lsd_sort(keys, r: int) -> np.ndarray:
     a = _u32(keys).copy()
     b = np.zeros_like(a)
