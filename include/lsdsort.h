@@ -310,7 +310,8 @@ LSDSORT_API int lsdsort_prepare_device(void);
  *      correct on any hardware;
  *   2  one returning LDS add per key, which needs the LDS to serve the colliding lanes of one
  *      wave instruction in lane order; the library verifies that on the device (a probe
- *      kernel at set-up) and silently uses form 0 if it does not hold;
+ *      kernel at set-up, in the workgroup sizes and LDS footprints of the sort's own kernels) and silently
+ *      uses form 0 if it does not hold;
  *  -1  (default) form 2 for 4- and 8-bit digits when the probe passes, form 0 otherwise.
  * lsdsort_rank_method reports the form a sort with this radix will use on the current device. */
 LSDSORT_API int lsdsort_set_rank_method(int method);

@@ -886,13 +886,16 @@ hipError_t launch_sample_keys(const uint32_t* keys, uint32_t n, uint32_t samples
 // compares ds_add_rtn_u32 against the ballot-derived stable rank over collision patterns from
 // "none" to "all 64 lanes on one word", with every CU busy.  Any disagreement clears *ok.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512) probe_lds_add_kernel(uint32_t iters, uint32_t* mismatches)
+// Run in the occupancy shapes of the kernels that rely on the property: 1024-thread workgroups holding 128 KiB of LDS
+// (one per CU, sixteen waves contending for the LDS pipe: the default 32768-key tile) and 512-thread workgroups
+// holding 74 KiB (two per CU); the tables sit at the front of the dynamic allocation, the rest only claims the space.
+__global__ void __launch_bounds__(1024) probe_lds_add_kernel(uint32_t iters, uint32_t* mismatches)
 {
-    __shared__ uint32_t s_cnt_raw[8 * 256];
-    __shared__ uint32_t s_ref_raw[8 * 256];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_probe_raw[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    volatile lds_u32* cnt = (volatile lds_u32*)s_cnt_raw + wave * 256;
-    volatile lds_u32* ref = (volatile lds_u32*)s_ref_raw + wave * 256;
+    const uint32_t waves = blockDim.x >> 6;
+    volatile lds_u32* cnt = (volatile lds_u32*)s_probe_raw + wave * 256;
+    volatile lds_u32* ref = (volatile lds_u32*)s_probe_raw + (waves + wave) * 256;
     for (uint32_t j = lane; j < 256; j += 64) {
         cnt[j] = 0;
         ref[j] = 0;
@@ -928,8 +931,14 @@ hipError_t probe_lds_add_lane_order(bool* ok, hipStream_t stream)
     if (e != hipSuccess) return e;
     uint32_t h_bad = 1;
     e = hipMemsetAsync(d_bad, 0, sizeof(uint32_t), stream);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(probe_lds_add_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(probe_lds_add_kernel, dim3(256 * 3), dim3(512), 0, stream, 600u, d_bad);
+        hipLaunchKernelGGL(probe_lds_add_kernel, dim3(256 * 3), dim3(1024), 128 * 1024, stream, 600u, d_bad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(probe_lds_add_kernel, dim3(256 * 3), dim3(512), 74 * 1024, stream, 600u, d_bad);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
