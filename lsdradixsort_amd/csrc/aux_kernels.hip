@@ -6,10 +6,14 @@
 #include "lsd_device.hpp"
 #include "lsd_kernels.hpp"
 
-// 8-bit digits, 8 regions: two copies of the 32 KiB of counters (even / odd lanes) and 512-thread workgroups:
-// 16 lanes per copy per LDS cycle group instead of 32 lowers the worst bank's load (0.313 -> 0.298 ms).
+// 8-bit digits, 8 regions: FOUR copies of the 32 KiB of counters, chosen by lane % 4, in 1024-thread workgroups (128 KiB
+// of LDS, one workgroup per CU).  LDS atomics of a wave instruction that meet on one word are served a lane per clock
+// (tools/ceiling/lds_atomic.hip), so what the copies buy is not speed on uniform keys (1, 2 and 4 copies measure within
+// 3 % of each other) but a bound on what a heavy value costs: with c copies at most 16/c lanes of a 16-lane group share a
+// word.  2 -> 4 copies: stage 1 on keys that are half zeros 1.02 -> 0.63 ms, on 90 % one value 1.66 -> 0.86 ms, before
+// the heavy values are counted by hand (add_field4 below).
 #ifndef LSD_R8_HIST_COPIES
-#define LSD_R8_HIST_COPIES 2
+#define LSD_R8_HIST_COPIES 4
 #endif
 #define LSD_R8_HIST_COPIES_VALUE LSD_R8_HIST_COPIES
 
@@ -240,7 +244,7 @@ hipError_t launch_scan_digit_counts(int radix_bits, int groups, const uint32_t* 
 constexpr int joint_copies(int radix_bits, bool wide, int counters_per_table)
 {
     if (counters_per_table < 1024) return 4;
-    return (radix_bits == 8 && !wide && counters_per_table <= 2048) ? LSD_R8_HIST_COPIES_VALUE : 1;   // 64 KiB of LDS at most
+    return (radix_bits == 8 && !wide && counters_per_table <= 2048) ? LSD_R8_HIST_COPIES_VALUE : 1;   // 128 KiB of LDS at most
 }
 
 // WIDE (4-bit digits, B = 4): one LDS atomic serves TWO passes.  The field of pass p is key bits
@@ -323,83 +327,21 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
         for (int p = 1; p < P; p++)
             atomicAdd(&word(p * F + digit_at<R + B>(k, (uint32_t)(R * p - B))) + copy, 1u);
     };
-    // A field on which the wave ALMOST agrees (sorted input: a digit boundary falls inside the wave's
-    // 256 keys about every other time) would put 30-odd lanes on each of two words, and same-address LDS
-    // atomics are served one lane per cycle.  Keys in order split a wave into a leading and a trailing
-    // group: when the first and the last lane's words cover 48 lanes or more, each group is counted by
-    // one add and only the lanes in between add for themselves.
-    auto edge_add = [&](uint32_t slot) {   // every lane of the wave active
-        const uint32_t lane = tid & 63u;
-        const uint32_t first = __builtin_amdgcn_readfirstlane(slot);
-        const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)slot, 63);
-        const unsigned long long mf = __ballot(slot == first);
-        const unsigned long long ml = __ballot(slot == last) & ~mf;
-        const uint32_t nf = (uint32_t)__builtin_popcountll(mf), nl = (uint32_t)__builtin_popcountll(ml);
-        if (nf + nl < 48u) {   // the usual case: lanes spread over many words
-            atomicAdd(&word(slot) + copy, 1u);
-            return;
-        }
-        if (lane == 0) atomicAdd(&word(first), nf);
-        if (nl != 0 && lane == 63u) atomicAdd(&word(last), nl);
-        if ((~(mf | ml) >> lane) & 1ull) atomicAdd(&word(slot) + copy, 1u);
+    // Field f of a key as a table slot (the tables follow each other in LDS).
+    auto slot_of = [&](int f, uint32_t k, uint32_t region0) -> uint32_t {
+        if (WIDE) return f == 0 ? ((region0 << 8) | (k & 0xFFu)) : (uint32_t)(f * FW) + digit_at<12>(k, (uint32_t)(8 * f - 4));
+        return f == 0 ? ((region0 << R) | digit_at<R>(k, 0)) : (uint32_t)(f * F) + digit_at<R + B>(k, (uint32_t)(R * f - B));
     };
-    // Four consecutive keys per lane, 256 consecutive keys per wave: when ALL of them agree on a field
-    // (sorted and nearly sorted input, small key ranges, dead digits) one lane adds 256; otherwise the
-    // field takes the plain path.  One agreement test per field per 16-byte load.
-    auto add_field4 = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-        const uint32_t s0 = __builtin_amdgcn_readfirstlane(a);
-        const bool same = (a == s0) & (b == s0) & (c == s0) & (d == s0);
-        if (__all(same)) {
-            if ((tid & 63u) == 0) atomicAdd(&word(s0), 256u);
-        } else {
-            // the lane's first key decides for all four whether the edge groups are worth looking for
-            const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
-            const unsigned long long mf = __ballot(a == s0);
-            const unsigned long long ml = __ballot(a == last) & ~mf;
-            if ((uint32_t)__builtin_popcountll(mf) + (uint32_t)__builtin_popcountll(ml) >= 48u) {
-                edge_add(a);
-                edge_add(b);
-                edge_add(c);
-                edge_add(d);
-            } else {
-                atomicAdd(&word(a) + copy, 1u);
-                atomicAdd(&word(b) + copy, 1u);
-                atomicAdd(&word(c) + copy, 1u);
-                atomicAdd(&word(d) + copy, 1u);
-            }
-        }
-    };
-    auto count_vec_checked = [&](const uint4& v, uint32_t region0) {   // every lane of the wave active
-        if (WIDE) {
-            add_field4((region0 << 8) | (v.x & 0xFFu), (region0 << 8) | (v.y & 0xFFu), (region0 << 8) | (v.z & 0xFFu),
-                       (region0 << 8) | (v.w & 0xFFu));
-#pragma unroll
-            for (int j = 1; j < NF; j++) {
-                const uint32_t sh = (uint32_t)(8 * j - 4);
-                add_field4(j * FW + digit_at<12>(v.x, sh), j * FW + digit_at<12>(v.y, sh), j * FW + digit_at<12>(v.z, sh),
-                           j * FW + digit_at<12>(v.w, sh));
-            }
-            return;
-        }
-        add_field4((region0 << R) | digit_at<R>(v.x, 0), (region0 << R) | digit_at<R>(v.y, 0), (region0 << R) | digit_at<R>(v.z, 0),
-                   (region0 << R) | digit_at<R>(v.w, 0));
-#pragma unroll
-        for (int p = 1; p < P; p++) {
-            const uint32_t sh = (uint32_t)(R * p - B);
-            add_field4(p * F + digit_at<R + B>(v.x, sh), p * F + digit_at<R + B>(v.y, sh), p * F + digit_at<R + B>(v.z, sh),
-                       p * F + digit_at<R + B>(v.w, sh));
-        }
-    };
-    auto looks_uniform = [&](uint32_t k) -> bool {
-        bool any = false;
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            const uint32_t d = digit_at<R>(k, (uint32_t)(R * p));
-            any = any || __all(d == __builtin_amdgcn_readfirstlane(d));
-        }
-        return any;
-    };
-
+    // HEAVY field values.  LDS atomics of one wave instruction that meet on one word are served a lane per clock
+    // (tools/ceiling/lds_atomic.hip: 63 clocks for a whole 16-lane group on one word against 7 for random words), so a value
+    // that a quarter, half or all of the keys carry -- zeros, a default value, constant or sorted input, dead digits -- would
+    // cost stage 1 several times its uniform-key time even with the copies.  A group of VPT vectors whose first keys show
+    // such a value in some field (lane 0's value, held by at least kHeavyLanes lanes) takes the careful path below: keys
+    // that hold a candidate value are counted in scalar registers (a compare and a population count per wave row, no LDS
+    // operation), everybody else adds for itself.  A group without one takes the plain path; both paths count every key
+    // exactly, the choice is speed only.
+    constexpr uint32_t kHeavyLanes = 16;
+    constexpr uint32_t kNoCandidate = 0xFFFFFFFFu;   // never a slot
     // Software-pipelined with TWO register buffers that swap roles (the loop is unrolled by two): while one group of
     // 16-byte loads goes through the LDS atomics the next is in flight, and the wait in front of a group is a COUNTED one
     // (`vmcnt(VPT)`: everything but the loads just issued).  For the compiler to count, the loads and the group they overtake
@@ -421,21 +363,86 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
             for (int u = 0; u < VPT; u++)
                 v[u] = make_uint4(to_sortable(v[u].x, xf), to_sortable(v[u].y, xf), to_sortable(v[u].z, xf), to_sortable(v[u].w, xf));
         }
-        // one look per group of VPT vectors (its first key) decides which path the group takes: both paths count every
-        // key exactly, the choice is speed only, and the test itself is a sixth of the plain path's instructions
-        const bool checked = looks_uniform(v[0].x);
+        // region0_keys is a multiple of the chunk (THREADS*4 keys), so a chunk is in one region
+        const uint32_t region_first = ((chunk_base + c) * (uint32_t)(THREADS * 4)) / region0_keys;
+        uint32_t cand[NF];
+        bool any = false;
 #pragma unroll
-        for (int u = 0; u < VPT; u++) {
-            // region0_keys is a multiple of the chunk (THREADS*4 keys), so the chunk is in one region
-            const uint32_t region0 = ((chunk_base + c + u) * (uint32_t)(THREADS * 4)) / region0_keys;
-            if (checked) {
-                count_vec_checked(v[u], region0);
-            } else {
+        for (int f = 0; f < NF; f++) {
+            const uint32_t s0 = slot_of(f, v[0].x, region_first);
+            const uint32_t first = __builtin_amdgcn_readfirstlane(s0);
+            const bool heavy = (uint32_t)__builtin_popcountll(__ballot(s0 == first)) >= kHeavyLanes;
+            cand[f] = heavy ? first : kNoCandidate;
+            any = any || heavy;
+        }
+        if (!any) {
+#pragma unroll
+            for (int u = 0; u < VPT; u++) {
+                const uint32_t region0 = ((chunk_base + c + u) * (uint32_t)(THREADS * 4)) / region0_keys;
                 count_key_plain(v[u].x, region0);
                 count_key_plain(v[u].y, region0);
                 count_key_plain(v[u].z, region0);
                 count_key_plain(v[u].w, region0);
             }
+            return;
+        }
+        // Per field: up to two candidate values c1, c2 whose holders are counted in scalar registers and added by one lane
+        // when the candidates change or the group ends.  The candidates are kept while they describe the vector at hand (16
+        // lanes or more of its first keys hold one of them: global heavy values never change) and are picked again from
+        // the vector's own first keys otherwise (sorted input: every vector has its own leading value and, where a digit
+        // boundary falls inside the wave's 256 keys, a trailing one = the first value that differs).
+        const uint32_t lane = tid & 63u;
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            uint32_t c1 = cand[f], c2 = kNoCandidate, held1 = 0, held2 = 0;   // uniform: scalar registers
+            auto flush = [&]() {
+                if (lane == 0) {
+                    if (held1) atomicAdd(&word(c1), held1);
+                    if (held2) atomicAdd(&word(c2), held2);
+                }
+                held1 = held2 = 0;
+            };
+#pragma unroll
+            for (int u = 0; u < VPT; u++) {
+                const uint32_t region0 = ((chunk_base + c + u) * (uint32_t)(THREADS * 4)) / region0_keys;
+                const uint32_t s4[4] = {slot_of(f, v[u].x, region0), slot_of(f, v[u].y, region0), slot_of(f, v[u].z, region0),
+                                        slot_of(f, v[u].w, region0)};
+                const uint32_t a = s4[0];
+                if ((uint32_t)__builtin_popcountll(__ballot(a == c1 || a == c2)) < kHeavyLanes) {
+                    flush();
+                    const uint32_t first = __builtin_amdgcn_readfirstlane(a);
+                    const unsigned long long mf = __ballot(a == first);
+                    c1 = c2 = kNoCandidate;
+                    if ((uint32_t)__builtin_popcountll(mf) >= kHeavyLanes) {
+                        c1 = first;
+                        const unsigned long long rest = ~mf;
+                        if (rest) {
+                            const uint32_t other = (uint32_t)__builtin_amdgcn_readlane((int)a, (int)__builtin_ctzll(rest));
+                            if ((uint32_t)__builtin_popcountll(__ballot(a == other)) >= 8u) c2 = other;
+                        }
+                    }
+                }
+                if (c1 == kNoCandidate) {
+                    atomicAdd(&word(s4[0]) + copy, 1u);
+                    atomicAdd(&word(s4[1]) + copy, 1u);
+                    atomicAdd(&word(s4[2]) + copy, 1u);
+                    atomicAdd(&word(s4[3]) + copy, 1u);
+                    continue;
+                }
+                const bool all4 = (s4[0] == c1) & (s4[1] == c1) & (s4[2] == c1) & (s4[3] == c1);
+                if (__all(all4)) {   // the wave's 256 keys agree (constant or sorted input, dead digits)
+                    held1 += 256u;
+                    continue;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const bool h1 = s4[q] == c1, h2 = s4[q] == c2;
+                    held1 += (uint32_t)__builtin_popcountll(__ballot(h1));
+                    held2 += (uint32_t)__builtin_popcountll(__ballot(h2));
+                    if (!(h1 || h2)) atomicAdd(&word(s4[q]) + copy, 1u);
+                }
+            }
+            flush();
         }
     };
     const uint32_t stride = gridDim.x * VPT;
@@ -497,7 +504,7 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
 }
 
 #ifndef LSD_R8_HIST_THREADS3
-#define LSD_R8_HIST_THREADS3 512
+#define LSD_R8_HIST_THREADS3 1024
 #endif
 #ifndef LSD_R4_HIST_THREADS
 #define LSD_R4_HIST_THREADS 512

@@ -40,8 +40,8 @@ constexpr size_t kAlign = 256;
 constexpr size_t kControlBytes = 256;            // u32[64]: [0] fault word
 constexpr uint32_t kMaxXcdChunk = 64;
 
-// Pass-0 regions are by position: R0 keys each, a multiple of the tile (hence of the histogram
-// kernel's 1024-key chunk), eight of them covering n.
+// Pass-0 regions are by position: R0 keys each, a multiple of the tile (every tile is a multiple of 4096 keys, the
+// histogram kernel's chunk at 1024 threads; launch_joint_histograms checks), eight of them covering n.
 uint32_t region0_keys(size_t n, size_t tile, int regions)
 {
     const size_t per = (n + regions - 1) / regions;

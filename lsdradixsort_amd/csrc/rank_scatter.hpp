@@ -175,6 +175,27 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         return k;
     };
 
+    // Heavy digit values of a wave row (see the rank phase): h1 = the value of lane 0 or of lane 32, whichever more lanes
+    // share, if at least kHeavy lanes do (a quarter of the wave: below that the atomics cost less than the care);
+    // h2 = the first value in the row that differs from it (kNoDigit if there is none).
+    constexpr uint32_t kHeavy = 16;
+    constexpr uint32_t kNoDigit = 0xFFFFFFFFu;
+    auto pick_heavy = [&](uint32_t d, uint32_t& h1, uint32_t& h2) -> bool {
+        const uint32_t a = __builtin_amdgcn_readfirstlane(d), b = (uint32_t)__builtin_amdgcn_readlane((int)d, 32);
+        const uint64_t ma = __ballot(d == a), mb = __ballot(d == b);
+        const uint32_t na = popc64_add(ma, 0u), nb = popc64_add(mb, 0u);
+        if ((na > nb ? na : nb) < kHeavy) return false;
+        h1 = na >= nb ? a : b;
+        const uint64_t rest = ~(na >= nb ? ma : mb);
+        h2 = rest != 0ull ? (uint32_t)__builtin_amdgcn_readlane((int)d, (int)__builtin_ctzll(rest)) : kNoDigit;
+        return true;
+    };
+    auto row_is_heavy = [&](uint32_t d) -> bool {
+        const uint32_t a = __builtin_amdgcn_readfirstlane(d), b = (uint32_t)__builtin_amdgcn_readlane((int)d, 32);
+        const uint32_t na = popc64_add(__ballot(d == a), 0u), nb = popc64_add(__ballot(d == b), 0u);
+        return (na > nb ? na : nb) >= kHeavy;
+    };
+
     // Housekeeping for the NEXT pass (it runs in the other status array): the grid's workgroups share the
     // rows out (one each when the grid is the row count).  Called after the look-back, where no load of the
     // wave is waited for any more: memory operations of a wave retire in issue order, so in front of the
@@ -309,8 +330,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             constexpr int NB = LSD_RANK_BATCHES, PER = K / NB;
             static_assert(K % NB == 0, "batches divide the rows");
             asm volatile("s_waitcnt vmcnt(%0)" : : "n"(K - PER) : "memory");
-            const uint32_t d_first = digit_of(key[0]);
-            if (!__all(d_first == __builtin_amdgcn_readfirstlane(d_first))) {
+            if (!row_is_heavy(digit_of(key[0]))) {   // heavy digits take the path below (phase 2)
 #pragma unroll
                 for (int b = 0; b < NB; b++) {
                     if (b > 0) {
@@ -357,24 +377,42 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     } else if (RANK == kRankLdsAdd) {
         // The returned old value is (same-digit keys in earlier rows) + (peers in lower lanes):
         // the K atomics are independent, so they issue back to back.
-        // A row whose 64 keys share one digit (constant or sorted input, dead digits) would
-        // serialise on one LDS word although its ranks are simply consecutive.  Only waves whose
-        // FIRST row is like that pay for testing every row; uniform random input takes the
-        // straight path, where the K atomics issue back to back.
-        const uint32_t d_first = digit_of(key[0]);
-        if (__all(d_first == __builtin_amdgcn_readfirstlane(d_first))) {
+        // HEAVY digits need care: LDS atomics of one wave instruction that meet on ONE word are served a lane per clock
+        // (tools/ceiling/lds_atomic.hip: 63 clocks when the sixteen lanes of every 16-lane group share a word, against
+        // 7.9 for random words), so a digit value that a quarter, half or all of the keys carry (zeros, a default value,
+        // constant or sorted input, dead digits) would slow the whole phase eightfold.  Only waves whose FIRST row shows
+        // such a value pay for the careful form: up to two heavy values h1, h2 are taken from that row, their keys are
+        // ranked from running counts kept in scalar registers (count so far + lower lanes with the same value: no LDS
+        // operation at all), everybody else still takes an atomic, and the counts are written to the wave's table at the
+        // end (no atomic ever touches those two words: a key either has the value or it has not).  Uniform random input
+        // takes the straight path, where the K atomics issue back to back.
+        uint32_t h1 = 0, h2 = 0;
+        if (pick_heavy(digit_of(key[0]), h1, h2)) {
+            // first every key that holds neither value takes its returning add (nothing else writes rank[] in this loop, so
+            // the adds issue one after the other and nothing waits for them) ...
 #pragma unroll
             for (int i = 0; i < K; i++) {
                 const uint32_t d = digit_of(key[i]);
-                const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-                if (__all(d == d0)) {
-                    const uint32_t before = s_cnt[wave * H + d0];
-                    rank[i] = before + lane;
-                    if (lane == 0) s_cnt[wave * H + d0] = before + 64u;
-                } else {
+                if (d != h1 && d != h2) {
                     rank[i] = __hip_atomic_fetch_add((lds_u32*)&s_cnt[wave * H + d], 1u, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
+            }
+            // ... then the holders are ranked from the running counts: vector and scalar ALU only
+            uint32_t c1 = 0, c2 = 0;
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                const uint32_t d = digit_of(key[i]);
+                const bool in1 = d == h1, in2 = d == h2;
+                const uint64_t m1 = __ballot(in1), m2 = __ballot(in2);
+                const uint32_t r1 = mbcnt_add(m1, c1), r2 = mbcnt_add(m2, c2);
+                rank[i] = in1 ? r1 : (in2 ? r2 : rank[i]);
+                c1 = popc64_add(m1, c1);
+                c2 = popc64_add(m2, c2);
+            }
+            if (lane == 0) {
+                s_cnt[wave * H + h1] = c1;
+                if (h2 != kNoDigit) s_cnt[wave * H + h2] = c2;
             }
         } else {
 #pragma unroll

@@ -146,6 +146,14 @@ def test_distributions(gpu, oracle_mod, r, rank_form):
         "high8": (base & 0xFF000000).astype(np.uint32),
         "mid": (base & 0x00FFFF00).astype(np.uint32),
         "two_values_far": np.where(base & 1, np.uint32(0xFFFFFFFF), np.uint32(0)).astype(np.uint32),
+        # heavy values: part of every wave row shares a digit (hand-counted in stage 1, ranked from scalar counts in the passes)
+        "half_zero": np.where((base >> np.uint32(13)) & np.uint32(1), base, np.uint32(0)).astype(np.uint32),
+        "ninety_pct_one_value": np.where((base % np.uint32(10)) != 0, np.uint32(0x80000001), base).astype(np.uint32),
+        "quarter_max": np.where((base & np.uint32(3)) == 0, np.uint32(0xFFFFFFFF), base).astype(np.uint32),
+        "four_values_per_digit": (base & np.uint32(0x03030303)).astype(np.uint32),
+        "three_heavy_values": np.where(base % np.uint32(7) < 2, np.uint32(5), np.where(base % np.uint32(7) < 4, np.uint32(0x05000005),
+                                       np.where(base % np.uint32(7) < 6, np.uint32(0xFF0000FF), base))).astype(np.uint32),
+        "runs_then_random": np.concatenate([np.repeat(base[: n // 600], 300)[: n // 2], base[n // 2:]]).astype(np.uint32)[:n],
     }
     for name, keys in cases.items():
         got = _sort_dev(gpu, keys, r)
@@ -197,6 +205,16 @@ def test_pairs_vs_stable_sort(gpu, oracle_mod, r, rank_form):
     # all keys equal: the payload must come back untouched
     k, v = _sort_dev(gpu, np.full(n, 7, dtype=np.uint32), r, 0, vals)
     assert np.array_equal(v, vals)
+    # heavy values (ranked from running scalar counts, not by LDS atomics): the order among equal keys is the rank itself
+    base = oracle_mod.mt19937_keys(n, 43)
+    for name, hk in (("half_zero", np.where((base >> np.uint32(9)) & np.uint32(1), base & np.uint32(0x00FF00FF), np.uint32(0))),
+                     ("ninety_pct", np.where((base % np.uint32(10)) != 0, np.uint32(0x80000001), base & np.uint32(0xFFFF))),
+                     ("two_values", np.where(base & np.uint32(1 << 17), np.uint32(0x11111111), np.uint32(0xEEEEEEEE))),
+                     ("runs", np.repeat(base[: n // 200 + 1] & np.uint32(0x0F0F0F0F), 200)[:n])):
+        hk = hk.astype(np.uint32)
+        ek, ev = oracle_mod.std_stable_sort_pairs(hk, vals)
+        k, v = _sort_dev(gpu, hk, r, 0, vals)
+        assert np.array_equal(k, ek) and np.array_equal(v, ev), (name, r)
 
 
 @pytest.mark.parametrize("r", [8, 4, 1])

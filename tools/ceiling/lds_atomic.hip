@@ -7,6 +7,7 @@
 //   random   : uniformly random word of a 2048-word table (what uniform keys give)
 //   random/2 : the same with every other lane switched off (cost per ACTIVE lane or per instruction?)
 //   same     : all 64 lanes on one word
+//   G words  : G distinct words per instruction with 64/G lanes on each (i: lanes interleaved, b: blocks of lanes)
 //   C copies : random word of a table replicated C times, the copy chosen by lane % C (stage 1's layout at C = 2)
 // Output: clocks per wave instruction per CU (100 MHz s_memrealtime scaled by the shader clock the runtime reports).
 // Build: hipcc --offload-arch=gfx950 -O3 -o lds_atomic lds_atomic.hip
@@ -35,6 +36,10 @@ __global__ void __launch_bounds__(1024) probe(uint32_t* __restrict__ sink, uint3
         x ^= x << 13; x ^= x >> 17; x ^= x << 5;
         if (PATTERN == 0) idx[u] = ((x >> 8) % (kWords / 32)) * 32 + (lane & 31u);
         else if (PATTERN == 3) idx[u] = (uint32_t)u;
+        else if (PATTERN >= 10) {   // G = 2^(PATTERN-10) distinct words per instruction, 64/G lanes on each (low-entropy digits)
+            constexpr uint32_t G = 1u << (PATTERN >= 10 ? PATTERN - 10 : 0);
+            idx[u] = (uint32_t)u * 64u + (PATTERN & 1 ? (lane % G) : (lane / (64u / G))) * 33u;   // odd: interleaved lanes, even: lane blocks
+        }
         else if (PATTERN >= 4) {   // 2^(PATTERN-3) copies of the table, chosen by lane: lanes of different classes never share a bank
             constexpr uint32_t C = 1u << (PATTERN >= 4 ? PATTERN - 3 : 0);
             idx[u] = ((x >> 8) % (kWords * 4 / C)) * C + (lane & (C - 1));
@@ -151,6 +156,12 @@ int main()
     run_mix<2>("mix 2 valu", cus, mhz, sink);
     run_mix<4>("mix 4 valu", cus, mhz, sink);
     run_mix<8>("mix 8 valu", cus, mhz, sink);
+    run<11, false>("2 words i", cus, mhz, sink);
+    run<12, false>("4 words b", cus, mhz, sink);
+    run<13, false>("8 words i", cus, mhz, sink);
+    run<14, false>("16 words b", cus, mhz, sink);
+    run<15, false>("32 words i", cus, mhz, sink);
+    run<12, true>("4 words b", cus, mhz, sink);
     run<3, false>("same", cus, mhz, sink);
     run<3, true>("same", cus, mhz, sink);
     return 0;

@@ -10,6 +10,7 @@ import argparse
 ap = argparse.ArgumentParser()
 ap.add_argument("--radix", type=int, nargs="*", default=[8, 4])
 ap.add_argument("--cfg", type=int, default=-1, help="tile configuration for every radix listed (-1: library default)")
+ap.add_argument("--only", nargs="*", default=None, help="case names to run")
 a = ap.parse_args()
 n = 1 << 28
 base = mt19937_keys(n, 0)
@@ -22,7 +23,14 @@ cases = {
     "high8_only": lambda: base & np.uint32(0xFF000000),
     "16_values_per_digit": lambda: base & np.uint32(0x0F0F0F0F),
     "small_range_2^20": lambda: base & np.uint32(0xFFFFF),
+    # heavy hitters: part of every wave row shares one digit, the rest is random (same-address LDS atomics of SOME lanes)
+    "half_zero_keys": lambda: np.where((base >> np.uint32(13)) & np.uint32(1), base, np.uint32(0)).astype(np.uint32),
+    "90pct_one_value": lambda: np.where((base % np.uint32(10)) != 0, np.uint32(0x80000001), base).astype(np.uint32),
+    "two_values": lambda: np.where(base & np.uint32(1 << 17), np.uint32(0x11111111), np.uint32(0xEEEEEEEE)).astype(np.uint32),
+    "four_values_per_digit": lambda: base & np.uint32(0x03030303),
 }
+if a.only:
+    cases = {k: v for k, v in cases.items() if k in a.only}
 for r in a.radix:
     if a.cfg >= 0:
         lsd.set_tile_config(r, a.cfg)
