@@ -270,6 +270,7 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
     // Narrow digits put 64 lanes on a few hundred words per pass: replicate the table so that
     // neighbouring lanes use different words (and banks); wide digits spread by themselves.
     constexpr int C = joint_copies(R, WIDE, FW);
+    static_assert(!WIDE || C == 1, "the wide flush reads one copy per counter");
     extern __shared__ __attribute__((aligned(16))) uint32_t s_joint[];   // [NF][FW][C]
     const uint32_t tid = threadIdx.x;
     const uint32_t copy = tid & (C - 1);
