@@ -320,6 +320,12 @@ LSDSORT_API int lsdsort_rank_method(int radix_bits);
  * one XCD so that neighbouring runs merge in one L2; 0 disables, default 16,
  * at most 64.  Speed only: results and forward progress never depend on it. */
 LSDSORT_API int lsdsort_set_xcd_chunk(int chunk);
+/* Dead passes.  A pass whose digit is the same for every key (small key ranges, dead high bits, constant input) is the
+ * identity; the device sees that in the digit counts of the upfront read and skips it (its workgroups leave at once), and
+ * one copy brings the keys back into the caller's buffer if an odd number of passes ran.  No host round trip, graph-
+ * capturable, results identical.  On by default for the uint32 sorts (keys and pairs, default algorithm); the typed
+ * sorts and 1-bit digits always run every pass.  0 switches it off (every pass runs, as the reference's do). */
+LSDSORT_API int lsdsort_set_pass_skipping(int on);
 /* Runtime tuning knob for experiments: selects among the compiled tile shapes (see
  * DESIGN.md); -1 restores the default.  Returns LSDSORT_ERR_INVALID_ARG if unknown. */
 LSDSORT_API int lsdsort_set_tile_config(int radix_bits, int config_id);

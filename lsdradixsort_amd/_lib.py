@@ -94,6 +94,7 @@ SIGNATURES = {
     "lsdsort_set_tile_config": (c_int, [c_int, c_int]),
     "lsdsort_prepare_device": (c_int, []),
     "lsdsort_set_xcd_chunk": (c_int, [c_int]),
+    "lsdsort_set_pass_skipping": (c_int, [c_int]),
     "lsdsort_set_rank_method": (c_int, [c_int]),
     "lsdsort_rank_method": (c_int, [c_int]),
 }

@@ -114,6 +114,11 @@ def set_xcd_chunk(chunk: int) -> None:
     check(lib().lsdsort_set_xcd_chunk(chunk), "lsdsort_set_xcd_chunk")
 
 
+def set_pass_skipping(on: bool) -> None:
+    """Skip passes whose digit is the same for every key (decided on the device from the digit counts; default on)."""
+    check(lib().lsdsort_set_pass_skipping(1 if on else 0), "lsdsort_set_pass_skipping")
+
+
 def set_rank_method(method: int) -> None:
     """-1 auto, 0 peer-mask forms only, 2 returning-LDS-add wherever the device probe passed."""
     check(lib().lsdsort_set_rank_method(method), "lsdsort_set_rank_method")

@@ -565,12 +565,35 @@ hipError_t launch_joint_histograms(int radix_bits, const uint32_t* keys, uint32_
 template <int REG>
 __global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __restrict__ counts, int bins, uint32_t n,
                                                           uint32_t tile_keys, uint32_t region0_keys, int passes,
-                                                          uint32_t* __restrict__ tables, uint32_t table_words)
+                                                          uint32_t* __restrict__ tables, uint32_t table_words,
+                                                          uint32_t* __restrict__ plan)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base[257];
+    __shared__ uint32_t s_const[kPlanWords];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const int pass = blockIdx.x;
+    if (plan) {
+        // The pass plan (PassParams::plan): a digit that is the same for every key (one bin holds all n) makes its pass
+        // the identity.  This workgroup looks at its own pass and at the ones before it, whose number of REAL passes says
+        // which buffer its keys are in.
+        if (tid < (uint32_t)kPlanWords) s_const[tid] = 0;
+        __syncthreads();
+        for (int q = 0; q <= pass; q++) {
+            uint32_t t = 0;
+            if (tid < (uint32_t)bins)
+                for (int x = 0; x < REG; x++) t += counts[(size_t)q * bins * REG + tid * REG + x];
+            if (tid < (uint32_t)bins && t == n) s_const[q] = 1;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t moved = 0;
+            for (int q = 0; q < pass; q++) moved += s_const[q] ? 0u : 1u;
+            plan[2 * pass] = s_const[pass];
+            plan[2 * pass + 1] = moved & 1u;
+            if (pass + 1 == passes) plan[2 * passes] = (moved + (s_const[pass] ? 0u : 1u)) & 1u;
+        }
+    }
     const uint32_t* c = counts + (size_t)pass * bins * REG;
     uint32_t* table = tables + (size_t)pass * table_words;
     uint32_t per_region[REG];
@@ -635,24 +658,48 @@ __global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __res
     }
 }
 
+// The keys (and payloads) back into the caller's buffer when the plan left them in the other one.
+__global__ void __launch_bounds__(1024) finish_plan_kernel(const uint32_t* __restrict__ plan_final, uint32_t* __restrict__ keys,
+                                                           const uint32_t* __restrict__ alt_keys, uint32_t* __restrict__ vals,
+                                                           const uint32_t* __restrict__ alt_vals, uint32_t n)
+{
+    if (*plan_final == 0) return;   // uniform: the usual case
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (size_t)gridDim.x * 1024) {
+        keys[i] = alt_keys[i];
+        if (vals) vals[i] = alt_vals[i];
+    }
+}
+
+hipError_t launch_finish_plan(const uint32_t* plan_final, uint32_t* keys, const uint32_t* alt_keys, uint32_t* vals,
+                              const uint32_t* alt_vals, uint32_t n, hipStream_t stream)
+{
+    if (!plan_final || !keys || !alt_keys || (vals && !alt_vals)) return hipErrorInvalidValue;
+    uint32_t blocks = (n + 4 * 1024 - 1) / (4 * 1024);
+    if (blocks > 512) blocks = 512;   // two workgroups per CU copy at full rate; the usual launch returns at once
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(finish_plan_kernel, dim3(blocks), dim3(1024), 0, stream, plan_final, keys, alt_keys, vals, alt_vals, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_scan_regions(int radix_bits, int passes, int regions, const uint32_t* counts, uint32_t n,
-                               uint32_t tile_keys, uint32_t region0_keys, uint32_t* tables, hipStream_t stream)
+                               uint32_t tile_keys, uint32_t region0_keys, uint32_t* tables, hipStream_t stream, uint32_t* plan)
 {
     if (radix_bits < 1 || radix_bits > 8 || (regions != 1 && regions != regions_for_radix(radix_bits))) return hipErrorInvalidValue;
+    if (plan && 2 * passes + 1 > kPlanWords) return hipErrorInvalidValue;
     const int bins = 1 << radix_bits;
     const uint32_t words = (uint32_t)region_table_words(radix_bits);
     if (regions == 1)
         hipLaunchKernelGGL((scan_regions_kernel<1>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
-                           region0_keys, passes, tables, words);
+                           region0_keys, passes, tables, words, plan);
     else if (regions == 8)
         hipLaunchKernelGGL((scan_regions_kernel<8>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
-                           region0_keys, passes, tables, words);
+                           region0_keys, passes, tables, words, plan);
     else if (regions == 16)
         hipLaunchKernelGGL((scan_regions_kernel<16>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
-                           region0_keys, passes, tables, words);
+                           region0_keys, passes, tables, words, plan);
     else
         hipLaunchKernelGGL((scan_regions_kernel<32>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
-                           region0_keys, passes, tables, words);
+                           region0_keys, passes, tables, words, plan);
     return hipGetLastError();
 }
 

@@ -87,6 +87,11 @@ struct PassParams {
     uint32_t* out;
     const uint32_t* vals_in;   // null: keys only
     uint32_t* vals_out;
+    // Chained form only, may be null.  plan[0] != 0: this pass's digit is the same for every key -- the pass is the
+    // identity and is skipped (its workgroups only clear the next pass's status rows).  plan[1] != 0: an odd number of
+    // passes before this one really ran, so the keys are in `out` and go to `in` (the roles swap).  Written by stage 2
+    // (scan_regions_kernel) from the digit counts; with it every pass is launched with the SAME in / out.
+    const uint32_t* plan;
     uint32_t n;
     uint32_t shift;            // bit_group * radix_bits
     uint32_t num_tiles;        // grid size: chained = upper bound on the regions' tile counts
@@ -154,7 +159,13 @@ hipError_t launch_joint_histograms(int radix_bits, const uint32_t* keys, uint32_
 // from plain digit histograms (`regions` = 1; passes may then be 1 for the multi-GPU partition).
 // counts: [passes][2^R][regions]; tables: [passes][region_table_words(R)].
 hipError_t launch_scan_regions(int radix_bits, int passes, int regions, const uint32_t* counts, uint32_t n,
-                               uint32_t tile_keys, uint32_t region0_keys, uint32_t* tables, hipStream_t stream);
+                               uint32_t tile_keys, uint32_t region0_keys, uint32_t* tables, hipStream_t stream,
+                               uint32_t* plan = nullptr);
+// The pass plan stage 2 writes when asked to (PassParams::plan): 2 words per pass, then plan[2 * passes] != 0 if the sorted
+// keys ended up in the second buffer.  launch_finish_plan copies them (and the payloads) back in that case.
+constexpr int kPlanWords = 2 * 16 + 1;   // up to 16 passes (2-bit digits)
+hipError_t launch_finish_plan(const uint32_t* plan_final, uint32_t* keys, const uint32_t* alt_keys, uint32_t* vals,
+                              const uint32_t* alt_vals, uint32_t n, hipStream_t stream);
 
 // Stage 1, staged: hist[t][d] per tile (BuildHistogramsKernel, .cu:660-702).
 hipError_t launch_tile_histograms(int radix_bits, const TileShape& shape, const uint32_t* keys,

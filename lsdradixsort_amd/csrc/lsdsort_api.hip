@@ -37,7 +37,13 @@ thread_local hipError_t g_last_hip = hipSuccess;
     } while (0)
 
 constexpr size_t kAlign = 256;
-constexpr size_t kControlBytes = 256;            // u32[64]: [0] fault word
+constexpr size_t kControlBytes = 256;            // u32[64]: [0] fault word, [16 .. 16 + kPlanWords) the pass plan
+constexpr size_t kPlanOffsetWords = 16;
+static_assert(kPlanOffsetWords + lsd::kPlanWords <= kControlBytes / sizeof(uint32_t), "the pass plan lives in the control block");
+std::atomic<int> g_skip_dead_passes{[] {                                // lsdsort_set_pass_skipping; LSDSORT_PASS_SKIPPING=0 starts it off
+    const char* e = getenv("LSDSORT_PASS_SKIPPING");
+    return (e && e[0] == '0') ? 0 : 1;
+}()};
 constexpr uint32_t kMaxXcdChunk = 64;
 
 // Pass-0 regions are by position: R0 keys each, a multiple of the tile (every tile is a multiple of 4096 keys, the
@@ -335,6 +341,13 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
 
     uint32_t* tables = nullptr;
     const size_t table_words = lsd::region_table_words(radix_bits);
+    // Passes whose digit is the same for every key are the identity: stage 2 sees that in the counts and writes a plan the
+    // pass kernels follow (lsd_kernels.hpp, PassParams::plan) -- small key ranges, dead digits and constant input then cost
+    // the passes that move something, plus one copy if their number is odd.  Not for typed sorts (their first and last
+    // pass carry the key transform) nor where the plan would not fit the control block.
+    uint32_t* plan = nullptr;
+    if (algorithm == LSDSORT_ALGO_ONESWEEP && !xf.on && 2 * passes + 1 <= lsd::kPlanWords && g_skip_dead_passes.load(std::memory_order_relaxed))
+        plan = control + kPlanOffsetWords;
     if (algorithm == LSDSORT_ALGO_ONESWEEP) {
         uint32_t* counts = reinterpret_cast<uint32_t*>(ws + L.counts);
         tables = reinterpret_cast<uint32_t*>(ws + L.tables);
@@ -365,7 +378,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
         }
         if (ev) LSD_TRY(ev->mark());
         LSD_HIP(lsd::launch_scan_regions(radix_bits, passes, L.regions, counts, (uint32_t)n, (uint32_t)shape->tile(),
-                                         L.region0, tables, stream));
+                                         L.region0, tables, stream, plan));
         if (ev) LSD_TRY(ev->mark());
     } else if (ev) {
         LSD_TRY(ev->mark());
@@ -403,6 +416,13 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             p.status_clear = pass + 1 < passes ? reinterpret_cast<uint32_t*>(ws + ((pass & 1) ? L.status : L.status_odd)) : nullptr;
             p.tickets = reinterpret_cast<uint32_t*>(ws + L.tickets) + (size_t)pass * lsd::kMaxRegions;
             p.parity = 0;
+            if (plan) {   // the same pair for every pass: the plan says which way round (and whether at all)
+                p.in = d_keys;
+                p.out = alt_keys;
+                p.vals_in = d_vals;
+                p.vals_out = alt_vals;
+                p.plan = plan + 2 * pass;
+            }
             if (xf.on && pass == 0) p.xin = xf;
             if (xf.on && pass + 1 == passes) p.xout = xf;
             if (ev) LSD_TRY(ev->arm_kernel_events());
@@ -430,7 +450,8 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
         t = vsrc; vsrc = vdst; vdst = t;
     }
     // 32 / radix_bits is even for every accepted radix: the result is back in d_keys/d_vals,
-    // as the reference relies on (.cu:905, .cu:1005).
+    // as the reference relies on (.cu:905, .cu:1005) -- unless the plan skipped an odd number of passes
+    if (plan) LSD_HIP(lsd::launch_finish_plan(plan + 2 * passes, d_keys, alt_keys, d_vals, alt_vals, (uint32_t)n, stream));
     return LSDSORT_OK;
 }
 
@@ -604,6 +625,12 @@ int lsdsort_set_xcd_chunk(int chunk)
 {
     if (chunk < 0 || chunk > (int)kMaxXcdChunk) return LSDSORT_ERR_INVALID_ARG;
     g_xcd_chunk.store((uint32_t)chunk, std::memory_order_relaxed);
+    return LSDSORT_OK;
+}
+
+int lsdsort_set_pass_skipping(int on)
+{
+    g_skip_dead_passes.store(on ? 1 : 0, std::memory_order_relaxed);
     return LSDSORT_OK;
 }
 

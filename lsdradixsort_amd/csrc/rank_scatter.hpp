@@ -207,6 +207,15 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         }
     };
 
+    // The pass plan (lsd_kernels.hpp): requested here, first looked at by the thread that is about to take the ticket (a
+    // skipped pass takes none) and by everybody behind the ticket's round trip -- a wait for these two words at the top of
+    // the kernel would add their latency to every tile (+1 % per sort, measured).
+    uint32_t plan_skip = 0, plan_swapped = 0;   // uniform
+    if (CHAINED && p.plan) {
+        plan_skip = p.plan[0];
+        plan_swapped = p.plan[1];
+    }
+
     // wave-private tables start at zero
 #pragma unroll
     for (int j = 0; j < (H + kWave - 1) / kWave; j++) {
@@ -239,7 +248,8 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             constexpr uint32_t NREG = (uint32_t)regions_for_radix(R);
             constexpr uint32_t PER_XCD = NREG >= (uint32_t)kXcds ? NREG / (uint32_t)kXcds : 1u;
             const uint32_t home = NREG >= (uint32_t)kXcds ? (xcc & (uint32_t)(kXcds - 1)) * PER_XCD + (blockIdx.x / (uint32_t)kXcds) % PER_XCD : 0u;
-            for (uint32_t a = 0; a < NREG; a++) {
+            // a skipped pass (plan) takes no ticket: "no tile" below sends every workgroup home
+            for (uint32_t a = 0; a < (plan_skip ? 0u : NREG); a++) {
                 const uint32_t x = (home + a) % NREG;
                 // Home region: ticket and extents in ONE round trip (the ticket is taken before the
                 // tile count is known; an over-run ticket of an exhausted region is harmless).
@@ -293,6 +303,20 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         tile_base = tile * (uint32_t)TILE;
         range_end = p.n;
     }
+    // The buffers of this pass: with a plan every pass is launched with the same pair, and the plan says whether the pass
+    // runs at all (a digit that is the same for every key makes it the identity) and which way round.
+    const uint32_t* in_keys = p.in;
+    uint32_t* out_keys = p.out;
+    const uint32_t* in_vals = p.vals_in;
+    uint32_t* out_vals = p.vals_out;
+    if (CHAINED && p.plan) {
+        if (plan_swapped) {
+            in_keys = p.out;
+            out_keys = const_cast<uint32_t*>(p.in);
+            in_vals = p.vals_out;
+            out_vals = const_cast<uint32_t*>(p.vals_in);
+        }
+    }
 #ifdef LSD_PHASE_STATS
     stat_row__ = tile;
     if (tid == 0 && p.stats) {
@@ -315,7 +339,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     bool ranked = false;   // wave-uniform: the full-tile fast path below has already ranked this wave's keys
     const uint32_t first = tile_base + wave * (uint32_t)(kWave * K) + lane;
     // one 64-bit base, constant offsets: an index sum per load would cost an address pair per load
-    const uint32_t* const keys_in = p.in + first;
+    const uint32_t* const keys_in = in_keys + first;
     if (full) {
 #pragma unroll
         for (int i = 0; i < K; i++) key[i] = keys_in[i * kWave];
@@ -524,7 +548,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     // fetched here and land while the keys are reordered.
     uint32_t val[PAIRS ? K : 1];
     auto load_vals = [&]() {
-        const uint32_t* const vals_in = p.vals_in + first;
+        const uint32_t* const vals_in = in_vals + first;
         if (full) {
 #pragma unroll
             for (int i = 0; i < K; i++) val[i] = vals_in[i * kWave];
@@ -723,7 +747,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                     const uint32_t d = digit_of(k);
                     if ((s2 & 3) == 0) dbytes[s2 / 4] = d;
                     else dbytes[s2 / 4] |= d << (8 * (s2 & 3));
-                    if (decltype(all_valid)::value || q < valid) p.out[s_gdelta[d] + q] = leaving(k);
+                    if (decltype(all_valid)::value || q < valid) out_keys[s_gdelta[d] + q] = leaving(k);
                     if ((s2 & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep at most eight slots in flight
                 }
             };
@@ -736,7 +760,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                     const uint32_t q = s2 * T + tid;
                     const uint32_t k = back[PREREAD ? s2 : 0];
                     const uint32_t d = digit_of(k);
-                    if (decltype(all_valid)::value || q < valid) p.out[s_gdelta[d] + q] = leaving(k);
+                    if (decltype(all_valid)::value || q < valid) out_keys[s_gdelta[d] + q] = leaving(k);
                 }
             };
             if (full) key_slots(std::true_type{});
@@ -763,7 +787,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                         const uint32_t q = round * CAP + slot;
                         const uint32_t k = s_keys[slot];
                         const uint32_t d = digit_of(k);
-                        if (decltype(all_valid)::value || q < valid) p.out[s_gdelta[d] + q] = leaving(k);
+                        if (decltype(all_valid)::value || q < valid) out_keys[s_gdelta[d] + q] = leaving(k);
                     }
                 }
             };
@@ -786,7 +810,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                     const uint32_t slot = s2 * T + tid;
                     const uint32_t q = round * CAP + slot;
                     const uint32_t d = (dbytes[s2 / 4] >> (8 * (s2 & 3))) & 0xFFu;
-                    if (decltype(all_valid)::value || q < valid) p.vals_out[s_gdelta[d] + q] = s_keys[slot];
+                    if (decltype(all_valid)::value || q < valid) out_vals[s_gdelta[d] + q] = s_keys[slot];
                     if ((s2 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
                 }
             };

@@ -160,6 +160,30 @@ def test_distributions(gpu, oracle_mod, r, rank_form):
         assert np.array_equal(got, np.sort(keys)), (name, r)
 
 
+@pytest.mark.parametrize("r", [8, 4, 2])
+def test_dead_passes_are_skipped_with_identical_results(gpu, oracle_mod, r):
+    """Passes whose digit is the same for every key are skipped on the device (plan written by stage 2): every number of
+    skipped passes (0 .. all), odd numbers (the copy back), dead digits below, between and above live ones, keys and
+    stable pairs, sizes around a tile; the same input with skipping switched off gives the same output."""
+    rng = np.random.default_rng(77 + r)
+    masks = [0xFFFFFFFF, 0x0000FFFF, 0x00FFFFFF, 0x000000FF, 0xFF000000, 0x00FF0000, 0xFF0000FF, 0x0000FF00, 0x00000000,
+             0x000FFFFF, 0x0F0F0F0F, 0xFFFF0000, 0x00FFFF00]
+    for case, mask in enumerate(masks):
+        n = int(rng.choice([1, 5, 4097, 32768, 32769, (1 << 20) + 3, (1 << 23) + 77])) if case % 3 else (1 << 21) + 11
+        keys = (oracle_mod.mt19937_keys(n, 100 + case) & np.uint32(mask)) | np.uint32(0x12345678 & ~mask & 0xFFFFFFFF)
+        keys = keys.astype(np.uint32)
+        vals = np.arange(n, dtype=np.uint32)
+        ek, ev = oracle_mod.std_stable_sort_pairs(keys, vals)
+        for skipping in (True, False):
+            gpu.set_pass_skipping(skipping)
+            try:
+                assert np.array_equal(_sort_dev(gpu, keys, r), ek), (hex(mask), n, r, skipping)
+                k, v = _sort_dev(gpu, keys, r, 0, vals)
+                assert np.array_equal(k, ek) and np.array_equal(v, ev), (hex(mask), n, r, skipping, "pairs")
+            finally:
+                gpu.set_pass_skipping(True)
+
+
 def test_randomised_shapes_of_input(gpu, oracle_mod):
     """Seeded sweep over sizes, radix widths and key shapes that steer the low-entropy paths of stage 1
     (wave-uniform fields, edge groups, few-valued digits) and of the rank phase: random bit masks, sorted /
