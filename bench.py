@@ -513,6 +513,45 @@ def main(argv=None):
                                    "in_use": lsd.rank_method(r),
                                    "opt_out": "lsdsort_set_rank_method(0) (include/lsdsort.h); method 2 is only used when the device probe passes"}
 
+        # Key distributions the reference never tests: made on the device from the workload's keys, sorted
+        # with the same call, each checked for sortedness.  ms per sort, best of 3 behind a warm-up.
+        def dist_ms(make):
+            src = make()
+            best = None
+            for i in range(4):
+                k = src.clone()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                lsd.GPULSDRadixSort(k, r, algorithm=algo, workspace=ws)
+                e1.record()
+                torch.cuda.synchronize()
+                if i:
+                    t = e0.elapsed_time(e1)
+                    best = t if best is None or t < best else best
+            u = k.to(torch.int64) & 0xFFFFFFFF
+            assert bool((u[1:] >= u[:-1]).all()), "distribution case not sorted"
+            assert lsd.lib().lsdsort_check_device(ws.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+            del src, k, u
+            return round(best, 4)
+
+        def sorted_keys():
+            k = master.clone()
+            lsd.GPULSDRadixSort(k, r, algorithm=algo, workspace=ws)
+            return k
+        low16 = master & 0xFFFF
+        extra["key_distributions_ms"] = {
+            "uniform": dist_ms(lambda: master),
+            "sorted": dist_ms(sorted_keys),
+            "constant": dist_ms(lambda: torch.full_like(master, 0x12345678)),
+            "one_live_byte": dist_ms(lambda: master & 0xFF),
+            "values_below_2p20": dist_ms(lambda: master & 0xFFFFF),
+            "half_zero": dist_ms(lambda: torch.where((master & 0x2000) != 0, master, torch.zeros_like(master))),
+            "ninety_pct_one_value": dist_ms(lambda: torch.where(low16 % 10 != 0, torch.full_like(master, -0x7FFFFFFF), master)),
+            "note": "2^%d keys each; dead passes skipped on the device, heavy values counted from scalar registers (DESIGN.md section 4.7)" % log2_keys,
+        }
+        del low16
+
         # Stage micro-benchmarks: the counterparts of the reference's TestBuildHistogram
         # (.cu:704, sweep .cu:1123-1136) and TestGPUPrefixSum (.cu:304, sweep .cu:1083-1092) harnesses, through the
         # stage-level C-ABI entries, for the reference's radix widths rs = {1, 2, 4, 8} (.cu:1055-1062).
