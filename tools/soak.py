@@ -17,7 +17,7 @@ while time.time() - t0 < budget_s and done < 20000:
     lg = rng.integers(lo_lg, hi_lg + 1)
     n = int(rng.integers(1 << max(lg - 1, 0), (1 << lg) + 1))
     r = int(rng.choice([8, 8, 8, 4, 4, 2, 1])) if n <= (1 << 20) else int(rng.choice([8, 8, 4]))
-    kind = int(rng.integers(0, 5))
+    kind = int(rng.integers(0, 7))
     s = streams[done % 2]
     with torch.cuda.stream(s):
         k = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda", generator=gen)
@@ -25,6 +25,14 @@ while time.time() - t0 < budget_s and done < 20000:
             k &= int(rng.integers(0, 1 << 31))
         if kind == 2:
             k = torch.sort(k).values
+        if kind == 5:   # heavy values: a random share of the keys on one value, another share on a second one
+            a, b = int(rng.integers(1, 100)), int(rng.integers(0, 50))
+            sel = torch.randint(0, 100, (n,), dtype=torch.int32, device="cuda", generator=gen)
+            k = torch.where(sel < a, torch.full_like(k, int(rng.integers(-(1 << 31), 1 << 31))), k)
+            k = torch.where(sel >= 100 - b, torch.full_like(k, int(rng.integers(-(1 << 31), 1 << 31))), k)
+        if kind == 6:   # dead bytes: whole digits the same for every key (skipped passes), odd and even numbers of them
+            keep = [0xFFFFFFFF, 0x0000FFFF, 0x00FFFFFF, 0xFF, 0x7F000000, 0x00FF0000, 0x7F0000FF, 0][int(rng.integers(0, 8))]
+            k = (k & keep) | (int(rng.integers(0, 1 << 31)) & ~keep & 0x7FFFFFFF)
         ws = lsd.alloc_workspace(n, r, kind == 3)
         if kind == 3 and r >= 4:
             v = torch.arange(n, dtype=torch.int32, device="cuda")
