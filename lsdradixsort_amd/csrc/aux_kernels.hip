@@ -366,15 +366,11 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
         }
         // region0_keys is a multiple of the chunk (THREADS*4 keys), so a chunk is in one region
         const uint32_t region_first = ((chunk_base + c) * (uint32_t)(THREADS * 4)) / region0_keys;
-        uint32_t cand[NF];
         bool any = false;
 #pragma unroll
         for (int f = 0; f < NF; f++) {
             const uint32_t s0 = slot_of(f, v[0].x, region_first);
-            const uint32_t first = __builtin_amdgcn_readfirstlane(s0);
-            const bool heavy = (uint32_t)__builtin_popcountll(__ballot(s0 == first)) >= kHeavyLanes;
-            cand[f] = heavy ? first : kNoCandidate;
-            any = any || heavy;
+            any = any || (uint32_t)__builtin_popcountll(__ballot(s0 == __builtin_amdgcn_readfirstlane(s0))) >= kHeavyLanes;
         }
         if (!any) {
 #pragma unroll
@@ -395,7 +391,7 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
         const uint32_t lane = tid & 63u;
 #pragma unroll
         for (int f = 0; f < NF; f++) {
-            uint32_t c1 = cand[f], c2 = kNoCandidate, held1 = 0, held2 = 0;   // uniform: scalar registers
+            uint32_t c1 = kNoCandidate, c2 = kNoCandidate, held1 = 0, held2 = 0;   // uniform: scalar registers; picked at the first vector
             auto flush = [&]() {
                 if (lane == 0) {
                     if (held1) atomicAdd(&word(c1), held1);
