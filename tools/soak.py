@@ -13,7 +13,7 @@ hi_lg = int(sys.argv[4]) if len(sys.argv) > 4 else 24
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 gen = torch.Generator(device="cuda"); gen.manual_seed(99)
 t0 = time.time(); done = 0
-while time.time() - t0 < budget_s and done < 20000:
+while time.time() - t0 < budget_s and done < 200000:
     lg = rng.integers(lo_lg, hi_lg + 1)
     n = int(rng.integers(1 << max(lg - 1, 0), (1 << lg) + 1))
     r = int(rng.choice([8, 8, 8, 4, 4, 2, 1])) if n <= (1 << 20) else int(rng.choice([8, 8, 4]))
