@@ -530,7 +530,10 @@ static hipError_t launch_joint_inst(const uint32_t* keys, uint32_t n, uint32_t r
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const uint32_t vec_chunks = aligned ? n / (THREADS * 4) : 0;
     uint32_t blocks = aligned ? (vec_chunks + kHistVecPerThread - 1) / kHistVecPerThread : (n + THREADS * 16 - 1) / (THREADS * 16);
-    const uint32_t cap = (uint32_t)(2048 * 256 / THREADS);   // enough waves to cover HBM latency
+#ifndef LSD_HIST_GRID_WAVES
+#define LSD_HIST_GRID_WAVES (2048 * 4)
+#endif
+    const uint32_t cap = (uint32_t)(LSD_HIST_GRID_WAVES * 64 / THREADS);   // enough waves to cover HBM latency (512 workgroups of 1024 threads)
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds_bytes, stream, keys, n, region0_keys, joint, vec_chunks, xf, first_key);
