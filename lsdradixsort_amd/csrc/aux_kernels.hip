@@ -565,7 +565,7 @@ template <int REG>
 __global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __restrict__ counts, int bins, uint32_t n,
                                                           uint32_t tile_keys, uint32_t region0_keys, int passes,
                                                           uint32_t* __restrict__ tables, uint32_t table_words,
-                                                          uint32_t* __restrict__ plan)
+                                                          uint32_t* __restrict__ plan, uint32_t* __restrict__ fault)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base[257];
@@ -609,8 +609,12 @@ __global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __res
     __syncthreads();
     for (uint32_t w = 0; w < wave; w++) incl += s_wave[w];
     const uint32_t digit_base = incl - total;
+    // Every key has exactly one digit: a pass's counts sum to n.  Counts that do not (a miscounting stage-1 variant:
+    // DESIGN.md section 4.5.2) would give the pass bases and extents that do not describe its input; say so in the fault
+    // word here, once, before any pass runs on them (the passes' destination guard keeps their stores in bounds).
+    if (fault && tid == (uint32_t)bins - 1u && incl != n) atomicOr(fault, 4u);
     if (tid < (uint32_t)bins) {
-        s_base[tid] = digit_base;
+        s_base[tid] = digit_base < n ? digit_base : n;   // extents below stay inside [0, n] whatever the counts say
         uint32_t run = digit_base;
 #pragma unroll
         for (int x = 0; x < REG; x++) {
@@ -625,8 +629,10 @@ __global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __res
         auto write_extents = [&](uint32_t* t, auto start_of) {
             uint32_t off = 0;
             for (int x = 0; x < REG; x++) {
-                const uint32_t lo = start_of(x), hi = start_of(x + 1);
-                const uint32_t len = hi - lo;
+                uint32_t lo = start_of(x), hi = start_of(x + 1);
+                lo = lo < n ? lo : n;
+                hi = hi < n ? hi : n;
+                const uint32_t len = hi > lo ? hi - lo : 0u;
                 const uint32_t tiles = (len + tile_keys - 1) / tile_keys;
                 t[x] = lo;
                 t[kMaxRegions + x] = len;
@@ -681,7 +687,8 @@ hipError_t launch_finish_plan(const uint32_t* plan_final, uint32_t* keys, const 
 }
 
 hipError_t launch_scan_regions(int radix_bits, int passes, int regions, const uint32_t* counts, uint32_t n,
-                               uint32_t tile_keys, uint32_t region0_keys, uint32_t* tables, hipStream_t stream, uint32_t* plan)
+                               uint32_t tile_keys, uint32_t region0_keys, uint32_t* tables, hipStream_t stream, uint32_t* plan,
+                               uint32_t* fault)
 {
     if (radix_bits < 1 || radix_bits > 8 || (regions != 1 && regions != regions_for_radix(radix_bits))) return hipErrorInvalidValue;
     if (plan && 2 * passes + 1 > kPlanWords) return hipErrorInvalidValue;
@@ -689,16 +696,16 @@ hipError_t launch_scan_regions(int radix_bits, int passes, int regions, const ui
     const uint32_t words = (uint32_t)region_table_words(radix_bits);
     if (regions == 1)
         hipLaunchKernelGGL((scan_regions_kernel<1>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
-                           region0_keys, passes, tables, words, plan);
+                           region0_keys, passes, tables, words, plan, fault);
     else if (regions == 8)
         hipLaunchKernelGGL((scan_regions_kernel<8>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
-                           region0_keys, passes, tables, words, plan);
+                           region0_keys, passes, tables, words, plan, fault);
     else if (regions == 16)
         hipLaunchKernelGGL((scan_regions_kernel<16>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
-                           region0_keys, passes, tables, words, plan);
+                           region0_keys, passes, tables, words, plan, fault);
     else
         hipLaunchKernelGGL((scan_regions_kernel<32>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
-                           region0_keys, passes, tables, words, plan);
+                           region0_keys, passes, tables, words, plan, fault);
     return hipGetLastError();
 }
 

@@ -158,9 +158,10 @@ hipError_t launch_joint_histograms(int radix_bits, const uint32_t* keys, uint32_
 // Stage 2, onesweep: region tables of every pass from the joint counts (`regions` = 16 or 32) or
 // from plain digit histograms (`regions` = 1; passes may then be 1 for the multi-GPU partition).
 // counts: [passes][2^R][regions]; tables: [passes][region_table_words(R)].
+// `fault` (may be null): the workspace fault word, raised (bit 2) if a pass's counts do not sum to n.
 hipError_t launch_scan_regions(int radix_bits, int passes, int regions, const uint32_t* counts, uint32_t n,
                                uint32_t tile_keys, uint32_t region0_keys, uint32_t* tables, hipStream_t stream,
-                               uint32_t* plan = nullptr);
+                               uint32_t* plan = nullptr, uint32_t* fault = nullptr);
 // The pass plan stage 2 writes when asked to (PassParams::plan): 2 words per pass, then plan[2 * passes] != 0 if the sorted
 // keys ended up in the second buffer.  launch_finish_plan copies them (and the payloads) back in that case.
 constexpr int kPlanWords = 2 * 16 + 1;   // up to 16 passes (2-bit digits)

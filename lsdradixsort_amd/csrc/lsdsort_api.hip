@@ -227,6 +227,22 @@ std::atomic<uint32_t> g_spin_limit{lsd::kSpinLimit};   // empty look-back polls 
 std::atomic<uint32_t> g_mute_row{0};                   // diagnostic builds only (LSD_FAULT_INJECT)
 std::atomic<int> g_rank_setting{-1};   // -1 auto, 0 mask forms only, 2 returning LDS add wherever probed ok
 
+#ifdef LSD_FAULT_INJECT
+// Diagnostic build only: counts[from] -= delta, counts[to] += delta behind stage 1 (word indices into the sort's
+// [pass][digit][region] count table), i.e. tables that do not describe the keys -- what a miscounting stage-1 variant
+// produces.  tests/test_fault_path.py drives the destination guard with it, once.
+struct CorruptCounts {
+    uint32_t from = 0, to = 0, delta = 0, keep_sum = 1;
+};
+std::mutex g_corrupt_mutex;
+CorruptCounts g_corrupt;
+__global__ void corrupt_counts_kernel(uint32_t* counts, CorruptCounts c)
+{
+    if (c.keep_sum) counts[c.from] -= c.delta;
+    counts[c.to] += c.delta;
+}
+#endif
+
 // The rank form a sort on `dev` with this radix will use.
 int resolve_rank_method(int dev, int radix_bits)
 {
@@ -377,8 +393,21 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             }
         }
         if (ev) LSD_TRY(ev->mark());
+#ifdef LSD_FAULT_INJECT
+        {   // diagnostic build only: move counts between two bins so that the tables no longer describe the keys
+            CorruptCounts c;
+            {
+                std::lock_guard<std::mutex> lock(g_corrupt_mutex);
+                c = g_corrupt;
+            }
+            if (c.delta) {
+                hipLaunchKernelGGL(corrupt_counts_kernel, dim3(1), dim3(1), 0, stream, counts, c);
+                LSD_HIP(hipGetLastError());
+            }
+        }
+#endif
         LSD_HIP(lsd::launch_scan_regions(radix_bits, passes, L.regions, counts, (uint32_t)n, (uint32_t)shape->tile(),
-                                         L.region0, tables, stream, plan));
+                                         L.region0, tables, stream, plan, control));
         if (ev) LSD_TRY(ev->mark());
     } else if (ev) {
         LSD_TRY(ev->mark());
@@ -572,7 +601,7 @@ const char* lsdsort_strerror(int status)
         case LSDSORT_ERR_WORKSPACE: return "workspace null, not 256-byte aligned, or too small";
         case LSDSORT_ERR_TOO_LARGE: return "n exceeds LSDSORT_MAX_KEYS";
         case LSDSORT_ERR_UNSUPPORTED: return "unsupported request (typed keys need radix 4 or 8; multi-GPU needs librccl)";
-        case LSDSORT_ERR_DEVICE_FAULT: return "a kernel gave up a bounded wait; output undefined";
+        case LSDSORT_ERR_DEVICE_FAULT: return "a kernel gave up a bounded wait or refused destinations outside the output (inconsistent counts); output undefined";
         case LSDSORT_ERR_COMM: return "RCCL call failed (see lsdsort_last_comm_error)";
         default: return "unknown lsdsort status";
     }
@@ -641,6 +670,20 @@ LSDSORT_API int lsdsort_debug_fault_inject(unsigned spin_limit, unsigned mute_ro
 {
     g_spin_limit.store(spin_limit ? spin_limit : lsd::kSpinLimit, std::memory_order_relaxed);
     g_mute_row.store(mute_row_plus_1, std::memory_order_relaxed);
+    return LSDSORT_OK;
+}
+#endif
+
+#ifdef LSD_FAULT_INJECT
+LSDSORT_API int lsdsort_debug_corrupt_counts(unsigned from_word, unsigned to_word, unsigned delta, unsigned keep_sum)
+{
+    CorruptCounts c;
+    c.from = from_word;
+    c.to = to_word;
+    c.delta = delta;
+    c.keep_sum = keep_sum;
+    std::lock_guard<std::mutex> lock(g_corrupt_mutex);
+    g_corrupt = c;
     return LSDSORT_OK;
 }
 #endif
@@ -944,7 +987,7 @@ static int partition_impl(const uint32_t* d_in, uint32_t* d_out, size_t n, int m
             LSD_HIP(lsd::launch_bucket_histogram(msb_bits, splitters, live, d_in, (uint32_t)n, hist, stream));
         else
             LSD_HIP(lsd::launch_digit_histograms(msb_bits, 1, shift, d_in, (uint32_t)n, hist, stream));
-        LSD_HIP(lsd::launch_scan_regions(msb_bits, 1, 1, hist, (uint32_t)n, (uint32_t)shape->tile(), 0, table, stream));
+        LSD_HIP(lsd::launch_scan_regions(msb_bits, 1, 1, hist, (uint32_t)n, (uint32_t)shape->tile(), 0, table, stream, nullptr, control));
         // the bucket sizes are final here: hand them out before the partition pass, so that a caller's count
         // exchange (multi-GPU step, sharded.hip) runs beside it
         LSD_HIP(lsd::launch_widen_counts(hist, d_counts, bins, stream));

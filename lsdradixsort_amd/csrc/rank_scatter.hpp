@@ -226,6 +226,10 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         }
     }
 
+    // "this tile stores nothing": set by a digit thread whose look-back gives up (bounded spin) or whose destinations
+    // would leave the output (destination guard), both below; read by everybody behind the look-back's barrier
+    if (tid == 0) s_misc[30] = 0;
+
     uint32_t tile;             // row of this tile in the status array
     uint32_t chain_pos = 0;    // position in its region's chain (chained form)
     uint32_t tile_base;        // index of the tile's first key
@@ -243,7 +247,6 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             uint32_t xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             uint32_t got = 0xFFFFFFFFu;
-            s_misc[30] = 0;   // set by a digit thread whose look-back gives up (bounded spin, below)
             // home regions of this XCD first (spread over them by block index), then everyone else's
             constexpr uint32_t NREG = (uint32_t)regions_for_radix(R);
             constexpr uint32_t PER_XCD = NREG >= (uint32_t)kXcds ? NREG / (uint32_t)kXcds : 1u;
@@ -646,6 +649,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             }
             if (tid < (uint32_t)H) {
                 uint32_t gbase;
+                uint64_t run_end;   // one past the last destination of this tile's keys of digit `tid`
                 if (CHAINED) {
                     uint32_t excl = 0;
                     if (chain_pos > 0) {
@@ -711,16 +715,28 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
                         if (tid == 0) LSD_SET(11, __builtin_amdgcn_s_memrealtime());
                     }
                     gbase = region_base + excl;
+                    run_end = (uint64_t)region_base + excl + pub_total;
                 } else {
                     gbase = p.global_off[(size_t)tile * H + tid];
+                    run_end = (uint64_t)gbase + pub_total;
+                }
+                // Destination guard.  Every store below goes to out[gbase + i], i < this tile's count of the digit, so
+                // run_end <= n keeps all of them inside the output whatever the tables hold.  The tables come from
+                // counts taken in another kernel (stage 1 / the caller's global_off): counts that do not describe the
+                // keys -- a miscounting histogram variant (the dist8.log fault), a caller's wrong
+                // table -- must end in LSDSORT_ERR_DEVICE_FAULT, never in a store outside the buffer.  The tile stores
+                // nothing; its prefix is already published, so nobody behind it waits.
+                if (run_end > (uint64_t)p.n) {
+                    if (p.fault) atomicOr(p.fault, 2u);
+                    s_misc[30] = 1u;
                 }
                 s_gdelta[tid] = gbase - local_off;
             }
         }
         lds_barrier();
         if (round == 0) LSD_STAMP(5);   // look-back (wave 0's digits) + barrier
-        if (CHAINED && round == 0 && s_misc[30] != 0u) {   // the look-back gave up (uniform): the sort has failed (fault word
-            clear_next();                                  // set); store nothing from a base that is not known
+        if (round == 0 && s_misc[30] != 0u) {   // the look-back gave up or the destination guard fired (uniform): the sort has
+            clear_next();                       // failed (fault word set); store nothing from a base that is not known
             return;
         }
 

@@ -1,9 +1,12 @@
 """Worker for tests/test_fault_path.py: runs in its own process with LSDSORT_LIB pointing at the diagnostic
 build liblsdsort_faultinject.so (make -C lsdradixsort_amd/csrc faultinject), never the product library.
 
-One status row is muted (its tile never publishes), the spin limit is small: the tiles behind it must give up
--- fault word raised, grid drained, no prefix published from a partial sum, nothing stored from an unknown
-base -- and the sort after it, on the same workspace, must be clean again.  Prints one JSON line.
+Modes keys / pairs: one status row is muted (its tile never publishes), the spin limit is small: the tiles behind it
+must give up -- fault word raised, grid drained, no prefix published from a partial sum, nothing stored from an unknown
+base.  Modes counts / counts_pairs / counts_sum: the digit counts are falsified behind stage 1, so the pass tables no
+longer describe the keys: the destination guard (rank_scatter.hpp) and the sum check (scan_regions_kernel) must turn
+that into LSDSORT_ERR_DEVICE_FAULT with every store inside the buffers.  In every mode the sort after it, on the same
+workspace, must be clean again.  Prints one JSON line.
 """
 import ctypes
 import json
@@ -24,8 +27,11 @@ L = lsd.lib()
 raw = ctypes.CDLL(lsd.LIB_PATH)
 raw.lsdsort_debug_fault_inject.argtypes = [ctypes.c_uint, ctypes.c_uint]
 raw.lsdsort_debug_fault_inject.restype = ctypes.c_int
+raw.lsdsort_debug_corrupt_counts.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
+raw.lsdsort_debug_corrupt_counts.restype = ctypes.c_int
 
-pairs = len(sys.argv) > 1 and sys.argv[1] == "pairs"
+mode = sys.argv[1] if len(sys.argv) > 1 else "keys"
+pairs = mode in ("pairs", "counts_pairs")
 r = 8
 n = (1 << 23) + 123
 GUARD = 1 << 16                     # int32 words on either side of the keys / bytes on either side of the workspace
@@ -58,9 +64,21 @@ def guards_intact():
 
 
 out = {"pairs": pairs, "n": n}
-# --- 1. a muted tile in the middle of region 0's chain, small spin limit
-MUTED_ROW = 5
-raw.lsdsort_debug_fault_inject(4000, MUTED_ROW + 1)
+if mode in ("keys", "pairs"):
+    # --- 1. a muted tile in the middle of region 0's chain, small spin limit
+    MUTED_ROW = 5
+    raw.lsdsort_debug_fault_inject(4000, MUTED_ROW + 1)
+else:
+    # --- 1'. counts that do not describe the keys (what a miscounting stage-1 variant leaves).  The count
+    # table is [pass][digit][region] (8-bit digits, 8 regions).  "counts": 1000 keys of the last pass's highest digit are
+    # booked on its lowest digit instead -- every sum is still n, but the bases of all higher digits are 1000 too large and the
+    # top digit's run would end 1000 keys behind the output: the passes' destination guard must refuse those stores.
+    # "counts_sum": five keys too many in pass 0 -- stage 2's sum check must say so.
+    word = lambda p, d, x: (p * 256 + d) * 8 + x
+    if mode == "counts_sum":
+        raw.lsdsort_debug_corrupt_counts(0, word(0, 0, 0), 5, 0)
+    else:
+        raw.lsdsort_debug_corrupt_counts(word(3, 255, 7), word(3, 0, 0), 1000, 1)
 torch.cuda.synchronize()
 t0 = time.time()
 st = L.lsdsort_u32_device_ex(keys.data_ptr(), vals.data_ptr() if pairs else None, ws.data_ptr(), wbytes, n, r, 0, stream)
@@ -70,6 +88,7 @@ out["drain_seconds"] = round(time.time() - t0, 3)
 out["guards_intact_after_fault"] = guards_intact()
 # --- 2. the same workspace, fault injection off: a clean sort
 raw.lsdsort_debug_fault_inject(0, 0)
+raw.lsdsort_debug_corrupt_counts(0, 0, 0, 1)
 keys.copy_(torch.from_numpy(host.view(np.int32)).cuda())
 if pairs:
     vals.copy_(torch.arange(n, dtype=torch.int32, device="cuda"))

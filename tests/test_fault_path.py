@@ -23,6 +23,7 @@ def test_product_library_has_no_fault_injection_hook():
 
     product = ctypes.CDLL(_lib.LIB_PATH)
     assert not hasattr(product, "lsdsort_debug_fault_inject")
+    assert not hasattr(product, "lsdsort_debug_corrupt_counts")
     assert "faultinject" not in os.path.basename(_lib.LIB_PATH)
 
 
@@ -42,5 +43,29 @@ def test_spin_expiry_gives_up_cleanly(mode):
     assert out["second_status"] == 0 and out["second_check"] == 0, out
     assert out["second_sorted"], "the sort after a faulted one (same workspace) is wrong"
     if mode == "pairs":
+        assert out["second_payload_stable"]
+    assert out["guards_intact_after_clean_sort"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["counts", "counts_pairs", "counts_sum"])
+def test_inconsistent_counts_never_store_out_of_bounds(mode):
+    """The round-2 memory fault (gpurun_out/dist8.log): an uncommitted stage-1 variant lost counts,
+    the pass tables stopped describing the keys and a top digit's run was stored behind the output.  Falsified counts
+    (diagnostic build: lsdsort_debug_corrupt_counts) must now end in LSDSORT_ERR_DEVICE_FAULT with the guard zones around
+    keys, payloads and workspace untouched -- by the destination guard of the passes ("counts": every sum still n) and by
+    stage 2's sum check ("counts_sum").  Provoked once per mode."""
+    assert os.path.exists(FAULT_LIB), "build the diagnostic library first: make -C lsdradixsort_amd/csrc faultinject"
+    env = dict(os.environ, LSDSORT_LIB=FAULT_LIB)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_fault_worker.py"), mode], env=env, capture_output=True,
+                       text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["launch_status"] == 0
+    assert out["check_status"] == -7, out
+    assert out["guards_intact_after_fault"], "stores left the buffers on inconsistent counts"
+    assert out["second_status"] == 0 and out["second_check"] == 0, out
+    assert out["second_sorted"]
+    if mode == "counts_pairs":
         assert out["second_payload_stable"]
     assert out["guards_intact_after_clean_sort"]
