@@ -36,10 +36,13 @@ typedef enum lsdsort_status {
     LSDSORT_ERR_NO_DEVICE = -2,    /* no HIP device / not gfx950; also num_gpus == 0 (no CPU path) */
     LSDSORT_ERR_HIP = -3,          /* a HIP runtime call failed; see lsdsort_last_hip_error()    */
     LSDSORT_ERR_WORKSPACE = -4,    /* workspace null, misaligned or smaller than required        */
-    LSDSORT_ERR_TOO_LARGE = -5,    /* n above LSDSORT_MAX_KEYS                                   */
+    LSDSORT_ERR_TOO_LARGE = -5,    /* n above LSDSORT_MAX_KEYS (a local argument check, never collective) */
     LSDSORT_ERR_UNSUPPORTED = -6,  /* valid request that cannot be served here (e.g. no librccl) */
-    LSDSORT_ERR_DEVICE_FAULT = -7, /* a kernel reported a bounded-spin timeout (see below)       */
-    LSDSORT_ERR_COMM = -8          /* an RCCL call failed; see lsdsort_last_comm_error()         */
+    LSDSORT_ERR_DEVICE_FAULT = -7, /* a kernel gave up a bounded wait, or refused destinations outside  */
+                                   /* the output because the counts do not describe the keys (see below) */
+    LSDSORT_ERR_COMM = -8,         /* a collective failed or a peer left it; lsdsort_last_comm_error() */
+    LSDSORT_ERR_CAPACITY = -9      /* sharded step: some rank's out_capacity is too small; EVERY rank  */
+                                   /* returns this before anything is exchanged (retry with *n_out)    */
 } lsdsort_status;
 
 /* Largest n any entry accepts: the chained tile prefix keeps 30 value bits per word.  The
@@ -75,9 +78,17 @@ LSDSORT_API int lsdsort_release_host_cache(void);
  * thread per device, one RCCL communicator made with ncclCommInitAll and kept for later calls): the array
  * is cut into num_gpus shards, each device runs lsdsort_sharded_u32_device (below) on its shard, and the
  * slices come back in rank order.  LSDSORT_ERR_NO_DEVICE if fewer gfx950 devices are visible,
- * LSDSORT_ERR_UNSUPPORTED if librccl cannot be loaded.  The one-process-per-GPU form (bench.py, a
+ * LSDSORT_ERR_UNSUPPORTED if librccl cannot be loaded.  Every device first sets itself up (buffers for its share plus a
+ * quarter, upload); the ranks then AGREE on a status before the first collective, so a device that fails there takes the call
+ * down with an error instead of leaving its peers in an all-gather; skewed keys repeat the step once with exact sizes.
+ * Calls with num_gpus > 1 take turns (one set of communicators per device count).  NOT YET RUN ON MORE THAN ONE DEVICE:
+ * the same code is exercised with virtual ranks on one GPU (lsdsort_u32_loopback).  The one-process-per-GPU form (bench.py, a
  * torch.distributed or MPI launcher) uses the lsdsort_comm_* entries directly. */
 LSDSORT_API int lsdsort_u32_ex(uint32_t* keys, size_t n, int radix_bits, int num_gpus);
+/* The num_gpus > 1 code of lsdsort_u32_ex with `virtual_gpus` (1, 2, 4, 8) VIRTUAL ranks on the current device (loopback
+ * transport, lsdsort_comm_create_loopback below): threads, set-up agreement, capacity retry, the step and the copy back run
+ * as they would on a multi-GPU node.  A rehearsal entry for one-GPU machines; the result is the sorted array all the same. */
+LSDSORT_API int lsdsort_u32_loopback(uint32_t* keys, size_t n, int radix_bits, int virtual_gpus);
 
 /* Key/value form, stable by key (BASELINE.json configs[4]); no reference counterpart. */
 LSDSORT_API int lsdsort_pairs_u32(uint32_t* keys, uint32_t* vals, size_t n);
@@ -240,6 +251,14 @@ typedef struct lsdsort_comm lsdsort_comm;
  * device it will sort on current.  Collective over the `world` ranks. */
 LSDSORT_API int lsdsort_comm_unique_id(void* id_out);
 LSDSORT_API int lsdsort_comm_create(const void* id, int world, int rank, lsdsort_comm** out);
+/* LOOPBACK: `world` (1, 2, 4 or 8) VIRTUAL ranks in this process on the CURRENT device -- out[0 .. world-1] receive their
+ * communicators.  Same step, same code; the all-gathers and the grouped exchange are device copies ordered by events
+ * instead of RCCL calls.  For machines with one GPU (the step's offsets, ordering, capacities and error paths can then be
+ * run with world > 1: tests/test_sharded_loopback.py) and for rehearsing a launcher.  Each virtual rank must be driven by
+ * its OWN host thread (the step is collective and waits for the others) and should be given its own stream.  A rank that
+ * fails inside a step marks the world aborted: its peers return LSDSORT_ERR_COMM instead of waiting, and the communicators
+ * are then only good for lsdsort_comm_destroy. */
+LSDSORT_API int lsdsort_comm_create_loopback(int world, lsdsort_comm** out);
 LSDSORT_API int lsdsort_comm_destroy(lsdsort_comm* comm);
 LSDSORT_API int lsdsort_comm_world(const lsdsort_comm* comm);
 LSDSORT_API int lsdsort_comm_rank(const lsdsort_comm* comm);
@@ -250,7 +269,10 @@ LSDSORT_API size_t lsdsort_sharded_workspace_bytes(size_t n_local_max, size_t ou
  * is the index of its first key in the global order, counts_matrix (may be NULL; world*world entries,
  * [src][dst]) says who sent what.  Collective; blocks the host only for the count matrix (the exchange and
  * the local sort stay queued on hip_stream).  If ANY rank would receive more than its out_capacity every rank
- * returns LSDSORT_ERR_TOO_LARGE before the exchange (capacities travel with the counts), so nobody hangs. */
+ * returns LSDSORT_ERR_CAPACITY before the exchange (capacities travel with the counts; *n_out then holds what this rank
+ * would have received), so nobody hangs and the caller can repeat the step with exact sizes.  Every OTHER error is this
+ * rank's alone (its peers may be inside a collective): the loopback transport then releases them with LSDSORT_ERR_COMM; over
+ * RCCL the launcher has to tear the job down, as with any failed rank of an RCCL job. */
 LSDSORT_API int lsdsort_sharded_u32_device(lsdsort_comm* comm, const uint32_t* d_keys_in, size_t n_local,
                                            uint32_t* d_out, size_t out_capacity, size_t* n_out,
                                            uint64_t* global_offset, uint64_t* counts_matrix,

@@ -8,8 +8,10 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "lsdsort.h"
 
@@ -88,6 +90,16 @@ inline comm_id unique_id()
 class communicator {
 public:
     communicator(const comm_id& id, int world, int rank) { check(lsdsort_comm_create(id.bytes, world, rank, &c_), "lsdsort_comm_create"); }
+    // `world` VIRTUAL ranks on the current device (lsdsort_comm_create_loopback): element r is rank r's communicator; each is to
+    // be driven by its own host thread.  For one-GPU machines: the step then runs with world > 1 (tests/cpp/test_sharded.cpp).
+    static std::vector<std::unique_ptr<communicator>> loopback(int world)
+    {
+        std::vector<lsdsort_comm*> raw((size_t)(world > 0 ? world : 1), nullptr);
+        check(lsdsort_comm_create_loopback(world, raw.data()), "lsdsort_comm_create_loopback");
+        std::vector<std::unique_ptr<communicator>> out;
+        for (lsdsort_comm* c : raw) out.emplace_back(new communicator(c));
+        return out;
+    }
     ~communicator() { lsdsort_comm_destroy(c_); }
     communicator(const communicator&) = delete;
     communicator& operator=(const communicator&) = delete;
@@ -115,6 +127,7 @@ public:
     }
 
 private:
+    explicit communicator(lsdsort_comm* adopted) : c_(adopted) {}
     lsdsort_comm* c_ = nullptr;
 };
 

@@ -38,6 +38,7 @@ class LsdsortTiming(ctypes.Structure):
 SIGNATURES = {
     "lsdsort_u32": (c_int, [c_u32p, c_size]),
     "lsdsort_u32_ex": (c_int, [c_u32p, c_size, c_int, c_int]),
+    "lsdsort_u32_loopback": (c_int, [c_u32p, c_size, c_int, c_int]),
     "lsdsort_pairs_u32": (c_int, [c_u32p, c_u32p, c_size]),
     "lsdsort_release_host_cache": (c_int, []),
     "lsdsort_workspace_bytes": (c_size, [c_size, c_int, c_int]),
@@ -70,6 +71,7 @@ SIGNATURES = {
                                                        ctypes.c_void_p, ctypes.c_void_p, c_size, ctypes.c_void_p]),
     "lsdsort_comm_unique_id": (c_int, [ctypes.c_void_p]),
     "lsdsort_comm_create": (c_int, [ctypes.c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "lsdsort_comm_create_loopback": (c_int, [c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "lsdsort_comm_destroy": (c_int, [ctypes.c_void_p]),
     "lsdsort_comm_world": (c_int, [ctypes.c_void_p]),
     "lsdsort_comm_rank": (c_int, [ctypes.c_void_p]),

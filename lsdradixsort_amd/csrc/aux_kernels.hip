@@ -241,10 +241,11 @@ hipError_t launch_scan_digit_counts(int radix_bits, int groups, const uint32_t* 
 // ------------------------------------------------------------------------------------------
 // Copies of every counter, chosen by lane (tid & (C-1)): small tables are replicated so that 64 lanes do not
 // pile onto a few hundred words.
-constexpr int joint_copies(int radix_bits, bool wide, int counters_per_table)
+constexpr int joint_copies(int radix_bits, bool wide, int counters_per_table, bool dma = false)
 {
     if (counters_per_table < 1024) return 4;
-    return (radix_bits == 8 && !wide && counters_per_table <= 2048) ? LSD_R8_HIST_COPIES_VALUE : 1;   // 128 KiB of LDS at most
+    if (radix_bits == 8 && !wide && counters_per_table <= 2048) return dma ? 2 : LSD_R8_HIST_COPIES_VALUE;   // 128 KiB of LDS at most
+    return 1;
 }
 
 // WIDE (4-bit digits, B = 4): one LDS atomic serves TWO passes.  The field of pass p is key bits
@@ -252,7 +253,16 @@ constexpr int joint_copies(int radix_bits, bool wide, int counters_per_table)
 // 8 bits) and 2j + 1 (its high 8 bits), so counting W_0..W_3 (W_0: position region | byte 0) and summing
 // 16 counters per output at flush time gives all eight tables from four atomics per key instead of eight:
 // the kernel is LDS-atomic-bound, so that is what its time follows (0.49 -> 0.30 ms at 2^28 keys).
-template <int R, int THREADS, bool WIDE = false>
+// DMA: the keys come in by LDS-DMA (global_load_lds_dwordx4, non-temporal: no VGPR destination, nothing kept in L2) into a
+// per-wave ring of kDmaBuffers groups of VPT KiB and are fetched from there with one ds_read_b128 per vector.  On this
+// part a read-only stream of LDS-DMA nt loads runs at 6.9-7.0 TB/s where plain 16-byte loads reach 5.2-5.4 and nt ones
+// 5.7-5.9 (tools/ceiling/ceiling2.hip, profiles/r3_ceilings.txt), and the vector-memory return path and 2 x VPT x 4 VGPRs are
+// free for the counting.  The ring costs LDS: 8-bit digits keep TWO lane-class copies of the counters (64 KiB) beside it.
+constexpr int kDmaBuffers = 3;
+template <int R, bool WIDE>
+constexpr int joint_dma_vpt() { return WIDE ? 4 : 2; }   // KiB per wave per group: 16 waves x 3 x 2 KiB (r = 8), 8 waves x 3 x 4 KiB (r = 4)
+
+template <int R, int THREADS, bool WIDE = false, bool DMA = false>
 __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                   uint32_t region0_keys, uint32_t* __restrict__ joint,
                                                                   uint32_t vec_chunks, const KeyTransform xf,
@@ -269,9 +279,9 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
     constexpr int FW = WIDE ? 4096 : F;       // counters per LDS table
     // Narrow digits put 64 lanes on a few hundred words per pass: replicate the table so that
     // neighbouring lanes use different words (and banks); wide digits spread by themselves.
-    constexpr int C = joint_copies(R, WIDE, FW);
+    constexpr int C = joint_copies(R, WIDE, FW, DMA);
     static_assert(!WIDE || C == 1, "the wide flush reads one copy per counter");
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_joint[];   // [NF][FW][C]
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_joint[];   // [NF][FW][C], then (DMA) the waves' rings
     const uint32_t tid = threadIdx.x;
     const uint32_t copy = tid & (C - 1);
     for (uint32_t j = tid; j < (uint32_t)(NF * FW * C); j += THREADS) s_joint[j] = 0;
@@ -355,17 +365,29 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
     const uint4* __restrict__ keys4 = reinterpret_cast<const uint4*>(keys);
     const uint32_t full_chunks = vec_chunks / VPT * VPT;
     auto load_group = [&](uint32_t c, uint4 (&v)[VPT]) {
+#ifdef LSD_HIST_NT_LOADS   // non-temporal loads: a read-only stream of them runs 8 % faster than plain loads (profiles/r3_ceilings.txt)
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* __restrict__ k4 = reinterpret_cast<const u32x4*>(keys);
+#pragma unroll
+        for (int u = 0; u < VPT; u++) {
+            const u32x4 t = __builtin_nontemporal_load(k4 + (size_t)(c + u) * THREADS + tid);
+            v[u] = make_uint4(t.x, t.y, t.z, t.w);
+        }
+#else
 #pragma unroll
         for (int u = 0; u < VPT; u++) v[u] = keys4[(size_t)(c + u) * THREADS + tid];
+#endif
     };
-    auto count_group = [&](uint32_t c, uint4 (&v)[VPT]) {
+    // region_of(u): pass-0 region of vector u of the group (a vector's 4 keys, and the 256 keys of the wave's row, share it)
+    auto count_vectors = [&](auto region_of, uint4 (&v)[DMA ? joint_dma_vpt<R, WIDE>() : VPT]) {
+        constexpr int NV = DMA ? joint_dma_vpt<R, WIDE>() : VPT;
         if (xf.on) {   // typed sorts count the "sortable" form of the keys (uniform branch); applied where the keys are used
 #pragma unroll
-            for (int u = 0; u < VPT; u++)
+            for (int u = 0; u < NV; u++)
                 v[u] = make_uint4(to_sortable(v[u].x, xf), to_sortable(v[u].y, xf), to_sortable(v[u].z, xf), to_sortable(v[u].w, xf));
         }
         // region0_keys is a multiple of the chunk (THREADS*4 keys), so a chunk is in one region
-        const uint32_t region_first = ((chunk_base + c) * (uint32_t)(THREADS * 4)) / region0_keys;
+        const uint32_t region_first = region_of(0);
         bool any = false;
 #pragma unroll
         for (int f = 0; f < NF; f++) {
@@ -374,8 +396,8 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
         }
         if (!any) {
 #pragma unroll
-            for (int u = 0; u < VPT; u++) {
-                const uint32_t region0 = ((chunk_base + c + u) * (uint32_t)(THREADS * 4)) / region0_keys;
+            for (int u = 0; u < NV; u++) {
+                const uint32_t region0 = region_of(u);
                 count_key_plain(v[u].x, region0);
                 count_key_plain(v[u].y, region0);
                 count_key_plain(v[u].z, region0);
@@ -400,8 +422,8 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
                 held1 = held2 = 0;
             };
 #pragma unroll
-            for (int u = 0; u < VPT; u++) {
-                const uint32_t region0 = ((chunk_base + c + u) * (uint32_t)(THREADS * 4)) / region0_keys;
+            for (int u = 0; u < NV; u++) {
+                const uint32_t region0 = region_of(u);
                 const uint32_t s4[4] = {slot_of(f, v[u].x, region0), slot_of(f, v[u].y, region0), slot_of(f, v[u].z, region0),
                                         slot_of(f, v[u].w, region0)};
                 const uint32_t a = s4[0];
@@ -442,30 +464,77 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
             flush();
         }
     };
-    const uint32_t stride = gridDim.x * VPT;
-    uint32_t c = blockIdx.x * VPT;
-    if (c < full_chunks) {
-        uint4 buf_a[VPT], buf_b[VPT];
-        load_group(c, buf_a);
-        for (;;) {
-            const uint32_t c1 = c + stride;
-            const bool more1 = c1 < full_chunks;
-            load_group(more1 ? c1 : c, buf_b);
-            count_group(c, buf_a);
-            if (!more1) break;
-            const uint32_t c2 = c1 + stride;
-            const bool more2 = c2 < full_chunks;
-            load_group(more2 ? c2 : c1, buf_a);
-            count_group(c1, buf_b);
-            if (!more2) break;
-            c = c2;
+    uint32_t tail_begin;   // first key the loops below leave to the tail
+    if constexpr (!DMA) {
+        auto count_group = [&](uint32_t c, uint4 (&v)[VPT]) {
+            count_vectors([&](int u) { return ((chunk_base + c + (uint32_t)u) * (uint32_t)(THREADS * 4)) / region0_keys; }, v);
+        };
+        const uint32_t stride = gridDim.x * VPT;
+        uint32_t c = blockIdx.x * VPT;
+        if (c < full_chunks) {
+            uint4 buf_a[VPT], buf_b[VPT];
+            load_group(c, buf_a);
+            for (;;) {
+                const uint32_t c1 = c + stride;
+                const bool more1 = c1 < full_chunks;
+                load_group(more1 ? c1 : c, buf_b);
+                count_group(c, buf_a);
+                if (!more1) break;
+                const uint32_t c2 = c1 + stride;
+                const bool more2 = c2 < full_chunks;
+                load_group(more2 ? c2 : c1, buf_a);
+                count_group(c1, buf_b);
+                if (!more2) break;
+                c = c2;
+            }
         }
+        tail_begin = full_chunks * (THREADS * 4);
+    } else {
+        // A wave streams GROUPS of DV consecutive pieces (a piece = 64 vectors = 256 keys = 1 KiB: what one LDS-DMA wave
+        // instruction moves; lane l's 16 bytes land at base + 16 l), strided over all waves of the grid.  kDmaBuffers groups
+        // are in flight per wave; the wait in front of a group is counted (the DMA completes in issue order), and a wave past
+        // its last group re-requests its first one so that the count stays the same (an L2 hit, not counted twice).
+        constexpr int DV = joint_dma_vpt<R, WIDE>();
+        constexpr int WAVES = THREADS / kWave;
+        typedef __attribute__((address_space(3))) void lds_void_t;
+        typedef __attribute__((address_space(1))) const void global_cvoid_t;
+        const uint32_t lane = tid & 63u, wave = tid >> 6;
+        uint4* const ring = reinterpret_cast<uint4*>(s_joint + NF * FW * C) + (size_t)wave * (kDmaBuffers * DV * 64);
+        const uint32_t groups = vec_chunks == 0 ? 0u : (n / 256u) / (uint32_t)DV;      // vec_chunks == 0: base not 16-byte aligned
+        const uint32_t stride = gridDim.x * (uint32_t)WAVES;
+        const uint32_t first = blockIdx.x * (uint32_t)WAVES + wave;
+        auto issue = [&](uint32_t g, int buf) {
+#pragma unroll
+            for (int u = 0; u < DV; u++)
+                __builtin_amdgcn_global_load_lds((global_cvoid_t*)(keys4 + ((size_t)g * DV + u) * 64 + lane),
+                                                 (lds_void_t*)(ring + (buf * DV + u) * 64), 16, 0, 2 /* nt */);
+        };
+        if (first < groups) {
+#pragma unroll
+            for (int b = 0; b < kDmaBuffers; b++) {
+                const uint32_t g = first + (uint32_t)b * stride;
+                issue(g < groups ? g : first, b);
+            }
+            int buf = 0;
+            for (uint32_t g = first; g < groups; g += stride) {
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"((kDmaBuffers - 1) * DV) : "memory");
+                uint4 v[DV];
+#pragma unroll
+                for (int u = 0; u < DV; u++) v[u] = ring[(buf * DV + u) * 64 + lane];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer is in registers: it may be refilled
+                const uint32_t ahead = g + (uint32_t)kDmaBuffers * stride;
+                issue(ahead < groups ? ahead : first, buf);
+                count_vectors([&](int u) { return (uint32_t)(((size_t)first_key + ((size_t)g * DV + (size_t)u) * 256u) / region0_keys); }, v);
+                buf = buf + 1 == kDmaBuffers ? 0 : buf + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may still be landing in LDS when the workgroup leaves
+        }
+        tail_begin = groups * (uint32_t)(DV * 256);
     }
     {
         // tail: the chunks past the last full group and the keys past the last chunk -- or every key when the base is not
         // 16-byte aligned (vec_chunks == 0) -- strided over the grid; a step's keys are consecutive, so a wave stays inside
         // one pass-0 region except at a boundary
-        const uint32_t tail_begin = full_chunks * (THREADS * 4);
         for (size_t i = (size_t)tail_begin + (size_t)blockIdx.x * THREADS + tid; i < n; i += (size_t)gridDim.x * THREADS)
             count_key_checked(xf.on ? to_sortable(keys[i], xf) : keys[i], (uint32_t)((first_key + i) / region0_keys));
     }
@@ -510,7 +579,11 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
 #define LSD_R8_HIST_THREADS 512
 #endif
 
-template <int R, int THREADS, bool WIDE = false>
+#ifndef LSD_HIST_DMA
+#define LSD_HIST_DMA 0   // 1 builds the LDS-DMA form (measured round 3: 0.32 ms against 0.27 ms -- the kernel is bound by the LDS pipe, and the DMA's LDS writes and the ds_read_b128 fetches are 10 % more work for it)
+#endif
+
+template <int R, int THREADS, bool WIDE = false, bool DMA = (LSD_HIST_DMA != 0)>
 static hipError_t launch_joint_inst(const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* joint,
                                     hipStream_t stream, const KeyTransform& xf, uint32_t first_key)
 {
@@ -518,9 +591,11 @@ static hipError_t launch_joint_inst(const uint32_t* keys, uint32_t n, uint32_t r
     constexpr int F = (1 << R) << region_bits_for_radix(R);
     constexpr int NF = WIDE ? P / 2 : P;
     constexpr int FW = WIDE ? 4096 : F;
-    constexpr int C = joint_copies(R, WIDE, FW);
-    constexpr size_t lds_bytes = (size_t)NF * FW * C * sizeof(uint32_t);
-    auto kernel = joint_histograms_kernel<R, THREADS, WIDE>;
+    constexpr int C = joint_copies(R, WIDE, FW, DMA);
+    constexpr size_t ring_bytes = DMA ? (size_t)(THREADS / kWave) * kDmaBuffers * joint_dma_vpt<R, WIDE>() * 1024 : 0;
+    constexpr size_t lds_bytes = (size_t)NF * FW * C * sizeof(uint32_t) + ring_bytes;
+    static_assert(lds_bytes <= 160 * 1024, "counters and rings must fit one CU's LDS");
+    auto kernel = joint_histograms_kernel<R, THREADS, WIDE, DMA>;
     if (lds_bytes > 64 * 1024) {
         static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -584,7 +584,7 @@ MsbLayout make_msb_layout(size_t n, int msb_bits)
 
 // internals other translation units of the library use (sharded.hip)
 namespace lsd {
-int sort_host_multi(uint32_t* keys, size_t n, int radix_bits, int num_gpus);   // sharded.hip
+int sort_host_multi(uint32_t* keys, size_t n, int radix_bits, int num_gpus, bool loopback);   // sharded.hip
 void set_last_hip_error(hipError_t e) { g_last_hip = e; }
 }  // namespace lsd
 
@@ -602,7 +602,8 @@ const char* lsdsort_strerror(int status)
         case LSDSORT_ERR_TOO_LARGE: return "n exceeds LSDSORT_MAX_KEYS";
         case LSDSORT_ERR_UNSUPPORTED: return "unsupported request (typed keys need radix 4 or 8; multi-GPU needs librccl)";
         case LSDSORT_ERR_DEVICE_FAULT: return "a kernel gave up a bounded wait or refused destinations outside the output (inconsistent counts); output undefined";
-        case LSDSORT_ERR_COMM: return "RCCL call failed (see lsdsort_last_comm_error)";
+        case LSDSORT_ERR_COMM: return "a collective failed or a peer left it (see lsdsort_last_comm_error)";
+        case LSDSORT_ERR_CAPACITY: return "a rank would receive more keys than its out_capacity (collective: every rank gets this, nothing was exchanged)";
         default: return "unknown lsdsort status";
     }
 }
@@ -855,8 +856,14 @@ int lsdsort_u32_ex(uint32_t* keys, size_t n, int radix_bits, int num_gpus)
 {
     if (num_gpus == 0) return LSDSORT_ERR_NO_DEVICE;     // the CPU path is the oracle, not the product
     if (num_gpus < 0) return LSDSORT_ERR_INVALID_ARG;
-    if (num_gpus > 1) return lsd::sort_host_multi(keys, n, radix_bits, num_gpus);   // sharded.hip: one thread per device, RCCL
+    if (num_gpus > 1) return lsd::sort_host_multi(keys, n, radix_bits, num_gpus, false);   // sharded.hip: one thread per device, RCCL
     return sort_host(keys, nullptr, n, radix_bits);
+}
+
+int lsdsort_u32_loopback(uint32_t* keys, size_t n, int radix_bits, int virtual_gpus)
+{
+    if (virtual_gpus == 1) return sort_host(keys, nullptr, n, radix_bits);
+    return lsd::sort_host_multi(keys, n, radix_bits, virtual_gpus, true);
 }
 
 int lsdsort_u32(uint32_t* keys, size_t n) { return lsdsort_u32_ex(keys, n, 8, 1); }

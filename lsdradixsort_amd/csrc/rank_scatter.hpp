@@ -36,8 +36,9 @@
 //      growing the LDS footprint.
 //   6. key/value: the payload takes the same LDS slot and the same dst.
 //
-// Tail tile: missing keys are 0xFFFFFFFF; they carry the highest digit and the highest
-// positions, so they sort to the end of the tile and are neither counted nor stored.
+// Tail tile: missing keys are 0xFFFFFFFF; they carry the highest digit any key of the tile can have (H - 1 for a bit
+// field, the number of live splitters under the splitter partition) and the highest positions, so they sort to the end of
+// the tile and are neither counted nor stored.
 #pragma once
 #include "lsd_device.hpp"
 #include "lsd_kernels.hpp"
@@ -484,9 +485,11 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             total += s_cnt[w * H + tid];
         }
     }
-    // digit totals that other tiles may see: the tail's padding is not data
+    // digit totals that other tiles may see: the tail's padding is not data.  The padding carries whatever digit 0xFFFFFFFF
+    // has: the highest, H - 1, for a bit field -- but under the splitter partition its bucket is the number of LIVE splitters,
+    // which may be lower (thresholds above every key are not compared); no real key has a higher digit either way.
     uint32_t pub_total = total;
-    if (tid == (uint32_t)(H - 1)) pub_total -= (uint32_t)TILE - valid;
+    if (tid == digit_of(0xFFFFFFFFu)) pub_total -= (uint32_t)TILE - valid;
 
     const uint32_t parity = p.parity;
     const uint32_t c_stale = code_stale(parity);

@@ -23,8 +23,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -167,10 +169,211 @@ ShardedLayout make_sharded_layout(size_t n_local_max, size_t out_capacity, int w
     return L;
 }
 
+
+// ---- the transport seam ---------------------------------------------------------------------------------------
+// Everything the step needs from the fabric: an all-gather of a few words per rank, and one grouped exchange of
+// sends and receives.  Two implementations: RCCL (one process per GPU, or one process with a host thread per
+// device), and a LOOPBACK -- W virtual ranks in one process on ONE device, each driven by its own host thread on its
+// own streams, exchanging by device copies -- so that the whole step (offsets, ordering, capacities, error paths) runs
+// with W in {2, 4, 8} where only one GPU exists (tests/test_sharded_loopback.py).  Collective calls are made by every
+// rank, in the same order; sizes in bytes.
+struct Transport {
+    virtual ~Transport() {}
+    virtual int all_gather(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) = 0;
+    virtual int group_start() = 0;
+    virtual int send(const void* src, size_t bytes, int peer, hipStream_t stream) = 0;
+    virtual int recv(void* dst, size_t bytes, int peer, hipStream_t stream) = 0;
+    virtual int group_end(hipStream_t stream) = 0;   // ALWAYS called after group_start, also when a send or receive failed: it reports the first error
+    // A rank that leaves a collective step early (a local error) tells the others, where the transport can: peers blocked
+    // in a collective of the loopback return LSDSORT_ERR_COMM instead of waiting for ever.  (An RCCL peer cannot be reached
+    // this way: there the ranks agree on a status BEFORE the first collective -- sort_host_multi -- or the launcher
+    // tears the job down.)
+    virtual void abort() {}
+};
+
+struct RcclTransport final : Transport {
+    ncclComm_t comm = nullptr;
+    int first_error = LSDSORT_OK;
+    int note(ncclResult_t r, const char* what)
+    {
+        if (r == ncclSuccess) return LSDSORT_OK;
+        std::snprintf(t_comm_error, sizeof(t_comm_error), "%s: %s", what, rccl().GetErrorString(r));
+        return LSDSORT_ERR_COMM;
+    }
+    int all_gather(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) override
+    {
+        return note(rccl().AllGather(send, recv, bytes_per_rank, ncclUint8, comm, stream), "ncclAllGather");
+    }
+    int group_start() override
+    {
+        first_error = LSDSORT_OK;
+        return note(rccl().GroupStart(), "ncclGroupStart");
+    }
+    int send(const void* src, size_t bytes, int peer, hipStream_t stream) override
+    {
+        if (first_error != LSDSORT_OK) return first_error;   // the group is closed by group_end either way
+        return first_error = note(rccl().Send(src, bytes, ncclUint8, peer, comm, stream), "ncclSend");
+    }
+    int recv(void* dst, size_t bytes, int peer, hipStream_t stream) override
+    {
+        if (first_error != LSDSORT_OK) return first_error;
+        return first_error = note(rccl().Recv(dst, bytes, ncclUint8, peer, comm, stream), "ncclRecv");
+    }
+    int group_end(hipStream_t) override
+    {
+        // the group is closed whatever happened inside it: an open group would swallow every later call of this thread
+        const int closed = note(rccl().GroupEnd(), "ncclGroupEnd");
+        return first_error != LSDSORT_OK ? first_error : closed;
+    }
+    ~RcclTransport() override
+    {
+        if (comm && rccl().ok) (void)rccl().CommDestroy(comm);
+    }
+};
+
+// The loopback world: state shared by the W virtual ranks of one process.
+struct LoopbackWorld {
+    int world = 1;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long long generation = 0;
+    bool aborted = false;
+    struct Op {
+        const void* src;
+        void* dst;
+        size_t bytes;
+        int peer;
+    };
+    struct Post {
+        const void* send = nullptr;   // all-gather
+        size_t bytes = 0;
+        std::vector<Op> sends, recvs; // grouped exchange
+        hipEvent_t ready = nullptr;   // "what I posted may be read" (recorded on my stream)
+        hipEvent_t done = nullptr;    // "I have queued my reads of everybody's data" (recorded on my stream)
+    } post[8];
+    // host barrier of the W rank threads; LSDSORT_ERR_COMM once any rank has aborted
+    int barrier()
+    {
+        std::unique_lock<std::mutex> lock(m);
+        if (aborted) return LSDSORT_ERR_COMM;
+        const unsigned long long gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            generation++;
+            cv.notify_all();
+            return LSDSORT_OK;
+        }
+        cv.wait(lock, [&] { return generation != gen || aborted; });
+        return generation != gen ? LSDSORT_OK : LSDSORT_ERR_COMM;
+    }
+    void abort()
+    {
+        std::lock_guard<std::mutex> lock(m);
+        aborted = true;
+        cv.notify_all();
+    }
+};
+
+struct LoopbackTransport final : Transport {
+    std::shared_ptr<LoopbackWorld> w;
+    int rank = 0;
+    bool in_group = false;
+    int first_error = LSDSORT_OK;
+    int fail(const char* what)
+    {
+        std::snprintf(t_comm_error, sizeof(t_comm_error), "loopback: %s", what);
+        return LSDSORT_ERR_COMM;
+    }
+    // Stream-ordered like the real thing: data is read once its owner's stream has reached the collective (ready), and
+    // an owner's later work waits until every reader has queued behind it (done).
+    int all_gather(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) override
+    {
+        LoopbackWorld::Post& mine = w->post[rank];
+        mine.send = send;
+        mine.bytes = bytes_per_rank;
+        SH_HIP(hipEventRecord(mine.ready, stream));
+        if (w->barrier() != LSDSORT_OK) return fail("a rank left the all-gather");
+        for (int p = 0; p < w->world; p++) {
+            if (w->post[p].bytes != bytes_per_rank) return fail("all-gather sizes differ between ranks");
+            SH_HIP(hipStreamWaitEvent(stream, w->post[p].ready, 0));
+            SH_HIP(hipMemcpyAsync(static_cast<char*>(recv) + (size_t)p * bytes_per_rank, w->post[p].send, bytes_per_rank,
+                                  hipMemcpyDeviceToDevice, stream));
+        }
+        SH_HIP(hipEventRecord(mine.done, stream));
+        if (w->barrier() != LSDSORT_OK) return fail("a rank left the all-gather");
+        for (int p = 0; p < w->world; p++) SH_HIP(hipStreamWaitEvent(stream, w->post[p].done, 0));
+        return LSDSORT_OK;
+    }
+    int group_start() override
+    {
+        in_group = true;
+        first_error = LSDSORT_OK;
+        w->post[rank].sends.clear();
+        w->post[rank].recvs.clear();
+        return LSDSORT_OK;
+    }
+    int send(const void* src, size_t bytes, int peer, hipStream_t) override
+    {
+        if (!in_group || peer < 0 || peer >= w->world || peer == rank) return first_error = fail("send outside a group or to a bad peer");
+        w->post[rank].sends.push_back({src, nullptr, bytes, peer});
+        return LSDSORT_OK;
+    }
+    int recv(void* dst, size_t bytes, int peer, hipStream_t) override
+    {
+        if (!in_group || peer < 0 || peer >= w->world || peer == rank) return first_error = fail("receive outside a group or from a bad peer");
+        w->post[rank].recvs.push_back({nullptr, dst, bytes, peer});
+        return LSDSORT_OK;
+    }
+    int group_end(hipStream_t stream) override
+    {
+        in_group = false;
+        if (first_error != LSDSORT_OK) {   // nothing of this group can be trusted: the peers are told, nobody waits for this rank
+            w->abort();
+            return first_error;
+        }
+        LoopbackWorld::Post& mine = w->post[rank];
+        SH_HIP(hipEventRecord(mine.ready, stream));
+        if (w->barrier() != LSDSORT_OK) return fail("a rank left the exchange");
+        // my k-th receive from peer p takes p's k-th send to me
+        int status = LSDSORT_OK;
+        for (size_t i = 0; i < mine.recvs.size() && status == LSDSORT_OK; i++) {
+            const LoopbackWorld::Op& r = mine.recvs[i];
+            size_t nth = 0;
+            for (size_t j = 0; j < i; j++) nth += mine.recvs[j].peer == r.peer ? 1 : 0;
+            const LoopbackWorld::Op* match = nullptr;
+            for (const LoopbackWorld::Op& s : w->post[r.peer].sends)
+                if (s.peer == rank && nth-- == 0) { match = &s; break; }
+            if (!match || match->bytes != r.bytes) { status = fail("a receive without a matching send of the same size"); break; }
+            if (hipStreamWaitEvent(stream, w->post[r.peer].ready, 0) != hipSuccess ||
+                hipMemcpyAsync(r.dst, match->src, r.bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) {
+                (void)hipGetLastError();
+                status = fail("device copy failed");
+            }
+        }
+        if (status == LSDSORT_OK && hipEventRecord(mine.done, stream) != hipSuccess) status = fail("event record failed");
+        if (status != LSDSORT_OK) {
+            w->abort();
+            return status;
+        }
+        if (w->barrier() != LSDSORT_OK) return fail("a rank left the exchange");
+        for (int p = 0; p < w->world; p++) SH_HIP(hipStreamWaitEvent(stream, w->post[p].done, 0));
+        return LSDSORT_OK;
+    }
+    void abort() override { w->abort(); }
+    ~LoopbackTransport() override
+    {
+        LoopbackWorld::Post& mine = w->post[rank];
+        if (mine.ready) (void)hipEventDestroy(mine.ready);
+        if (mine.done) (void)hipEventDestroy(mine.done);
+        mine.ready = mine.done = nullptr;
+    }
+};
+
 }  // namespace
 
 struct lsdsort_comm {
-    ncclComm_t comm = nullptr;
+    Transport* transport = nullptr;
     int world = 1, rank = 0, device = 0;
     hipStream_t side = nullptr;
     hipEvent_t counts_ready = nullptr;
@@ -221,9 +424,13 @@ int lsdsort_comm_create(const void* id, int world, int rank, lsdsort_comm** out)
     c->rank = rank;
     ncclUniqueId nid;
     std::memcpy(&nid, id, sizeof(nid));
-    ncclResult_t r = rccl().CommInitRank(&c->comm, world, nid, rank);
+    RcclTransport* t = new RcclTransport;
+    c->transport = t;
+    ncclResult_t r = rccl().CommInitRank(&t->comm, world, nid, rank);
     if (r != ncclSuccess) {
         std::snprintf(t_comm_error, sizeof(t_comm_error), "ncclCommInitRank: %s", rccl().GetErrorString(r));
+        t->comm = nullptr;
+        delete t;
         delete c;
         return LSDSORT_ERR_COMM;
     }
@@ -236,6 +443,40 @@ int lsdsort_comm_create(const void* id, int world, int rank, lsdsort_comm** out)
     return LSDSORT_OK;
 }
 
+int lsdsort_comm_create_loopback(int world, lsdsort_comm** out)
+{
+    if (!out || log2_world(world) < 0) return LSDSORT_ERR_INVALID_ARG;
+    for (int i = 0; i < world; i++) out[i] = nullptr;
+    SH_TRY(lsdsort_prepare_device());
+    auto shared = std::make_shared<LoopbackWorld>();
+    shared->world = world;
+    int status = LSDSORT_OK;
+    for (int i = 0; i < world && status == LSDSORT_OK; i++) {
+        lsdsort_comm* c = new lsdsort_comm;
+        c->world = world;
+        c->rank = i;
+        LoopbackTransport* t = new LoopbackTransport;
+        t->w = shared;
+        t->rank = i;
+        c->transport = t;
+        out[i] = c;
+        if (hipEventCreateWithFlags(&shared->post[i].ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&shared->post[i].done, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            status = LSDSORT_ERR_HIP;
+        } else {
+            status = finish_comm(c);
+        }
+    }
+    if (status != LSDSORT_OK) {
+        for (int i = 0; i < world; i++) {
+            (void)lsdsort_comm_destroy(out[i]);
+            out[i] = nullptr;
+        }
+    }
+    return status;
+}
+
 int lsdsort_comm_destroy(lsdsort_comm* c)
 {
     if (!c) return LSDSORT_OK;
@@ -246,7 +487,7 @@ int lsdsort_comm_destroy(lsdsort_comm* c)
     if (c->counts_ready) (void)hipEventDestroy(c->counts_ready);
     if (c->sample_ready) (void)hipEventDestroy(c->sample_ready);
     if (c->side) (void)hipStreamDestroy(c->side);
-    if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+    delete c->transport;
     if (switched) (void)hipSetDevice(prev);
     (void)hipGetLastError();
     delete c;
@@ -318,9 +559,26 @@ int lsdsort_sharded_u32_device(lsdsort_comm* c, const uint32_t* d_keys_in, size_
                                          workspace_bytes, radix_bits, LSDSORT_PARTITION_MSB, hip_stream);
 }
 
+static int sharded_step(lsdsort_comm* c, const uint32_t* d_keys_in, size_t n_local, uint32_t* d_out,
+                        size_t out_capacity, size_t* n_out, uint64_t* global_offset, uint64_t* counts_matrix,
+                        void* d_workspace, size_t workspace_bytes, int radix_bits, int partition, void* hip_stream);
+
 int lsdsort_sharded_u32_device_ex(lsdsort_comm* c, const uint32_t* d_keys_in, size_t n_local, uint32_t* d_out,
                                   size_t out_capacity, size_t* n_out, uint64_t* global_offset, uint64_t* counts_matrix,
                                   void* d_workspace, size_t workspace_bytes, int radix_bits, int partition, void* hip_stream)
+{
+    if (!c) return LSDSORT_ERR_INVALID_ARG;
+    const int status = sharded_step(c, d_keys_in, n_local, d_out, out_capacity, n_out, global_offset, counts_matrix, d_workspace,
+                                    workspace_bytes, radix_bits, partition, hip_stream);
+    // LSDSORT_ERR_CAPACITY is the one error every rank returns together (decided from the gathered capacities, before the
+    // exchange).  Any other failure is this rank's alone: it leaves the step while its peers may be inside a collective.
+    if (status != LSDSORT_OK && status != LSDSORT_ERR_CAPACITY) c->transport->abort();
+    return status;
+}
+
+static int sharded_step(lsdsort_comm* c, const uint32_t* d_keys_in, size_t n_local, uint32_t* d_out,
+                        size_t out_capacity, size_t* n_out, uint64_t* global_offset, uint64_t* counts_matrix,
+                        void* d_workspace, size_t workspace_bytes, int radix_bits, int partition, void* hip_stream)
 {
     if (!c || !n_out || !global_offset) return LSDSORT_ERR_INVALID_ARG;
     if (partition != LSDSORT_PARTITION_MSB && partition != LSDSORT_PARTITION_SPLITTERS) return LSDSORT_ERR_INVALID_ARG;
@@ -338,7 +596,7 @@ int lsdsort_sharded_u32_device_ex(lsdsort_comm* c, const uint32_t* d_keys_in, si
     uint64_t* d_vec = reinterpret_cast<uint64_t*>(ws + L.vec);
     uint64_t* d_all = reinterpret_cast<uint64_t*>(ws + L.all);
     uint32_t* d_send = reinterpret_cast<uint32_t*>(ws + L.send);
-    Rccl& R = rccl();
+    Transport& T = *c->transport;
 
     // 0.  splitter rule only: a regular sample of every shard to every rank (one more host wait, ahead of the partition);
     //     each rank then cuts the sorted (key, source rank) sample into W equal parts and derives ITS thresholds
@@ -350,7 +608,7 @@ int lsdsort_sharded_u32_device_ex(lsdsort_comm* c, const uint32_t* d_keys_in, si
         SH_HIP(lsd::launch_sample_keys(d_keys_in, (uint32_t)n_local, (uint32_t)S, d_samp, stream));
         SH_HIP(hipEventRecord(c->sample_ready, stream));
         SH_HIP(hipStreamWaitEvent(c->side, c->sample_ready, 0));
-        SH_NCCL(R.AllGather(d_samp, d_samp_all, (size_t)(1 + S), ncclUint32, c->comm, c->side));
+        SH_TRY(T.all_gather(d_samp, d_samp_all, (size_t)(1 + S) * sizeof(uint32_t), c->side));
         SH_HIP(hipMemcpyAsync(c->h_samples, d_samp_all, (size_t)W * (1 + S) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->side));
         SH_HIP(hipStreamSynchronize(c->side));
         SH_TRY(lsdsort_sharded_thresholds(c->h_samples, W, S, c->rank, thresholds));
@@ -364,7 +622,7 @@ int lsdsort_sharded_u32_device_ex(lsdsort_comm* c, const uint32_t* d_keys_in, si
         SH_TRY(lsd::partition_with_event(d_keys_in, d_send, n_local, bits, d_vec, ws + L.part_ws, L.part_ws_bytes, stream, c->counts_ready));
     SH_HIP(hipStreamWaitEvent(c->side, c->counts_ready, 0));
     SH_HIP(lsd::launch_store_u64(d_vec + W, (uint64_t)out_capacity, c->side));
-    SH_NCCL(R.AllGather(d_vec, d_all, (size_t)(W + 1), ncclUint64, c->comm, c->side));
+    SH_TRY(T.all_gather(d_vec, d_all, (size_t)(W + 1) * sizeof(uint64_t), c->side));
     SH_HIP(hipMemcpyAsync(c->h_all, d_all, (size_t)W * (W + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->side));
     SH_HIP(hipStreamSynchronize(c->side));                      // the step's only host wait
 
@@ -382,17 +640,19 @@ int lsdsort_sharded_u32_device_ex(lsdsort_comm* c, const uint32_t* d_keys_in, si
     if (counts_matrix) std::memcpy(counts_matrix, m, (size_t)W * W * sizeof(uint64_t));
     *n_out = (size_t)total;
     *global_offset = offset;
-    if (!fits) return LSDSORT_ERR_TOO_LARGE;                   // every rank returns this, none has posted a send
+    if (!fits) return LSDSORT_ERR_CAPACITY;                    // every rank returns this, none has posted a send
 
-    // 3.  one grouped exchange, every peer at once; my own bucket stays on the device
-    SH_NCCL(R.GroupStart());
+    // 3.  one grouped exchange, every peer at once; my own bucket stays on the device.  The group is closed whatever
+    //     happens inside it (an open RCCL group would swallow every later call of this thread); group_end reports the
+    //     first error of the group.
+    SH_TRY(T.group_start());
     for (int step = 1; step < W; step++) {
         const int to = (c->rank + step) % W, from = (c->rank - step + W) % W;   // a different partner pair per step
         const uint64_t ns = m[c->rank * W + to], nr = m[from * W + c->rank];
-        if (ns) SH_NCCL(R.Send(d_send + send_off[to], (size_t)ns, ncclUint32, to, c->comm, stream));
-        if (nr) SH_NCCL(R.Recv(d_out + recv_off[from], (size_t)nr, ncclUint32, from, c->comm, stream));
+        if (ns && T.send(d_send + send_off[to], (size_t)ns * sizeof(uint32_t), to, stream) != LSDSORT_OK) break;
+        if (nr && T.recv(d_out + recv_off[from], (size_t)nr * sizeof(uint32_t), from, stream) != LSDSORT_OK) break;
     }
-    SH_NCCL(R.GroupEnd());
+    SH_TRY(T.group_end(stream));
     const uint64_t mine = m[c->rank * W + c->rank];
     if (mine)
         SH_HIP(hipMemcpyAsync(d_out + recv_off[c->rank], d_send + send_off[c->rank], (size_t)mine * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
@@ -415,100 +675,196 @@ int lsdsort_sharded_check_device(void* d_workspace, size_t n_local, size_t out_c
 }  // extern "C"
 
 // ---- lsdsort_u32_ex(keys, n, radix_bits, num_gpus > 1): one process, one host thread per device ------------------
+// Also lsdsort_u32_loopback: the same code with `num_gpus` VIRTUAL ranks on the current device (loopback transport), so
+// that threads, set-up agreement, capacity retry, step and copy back run where only one GPU exists.
 namespace lsd {
 
 namespace {
+// Host-side agreement of the set's rank threads: everybody contributes a status and gets the worst one back.  Used in
+// front of the first collective of a call, so that a rank whose set-up failed (no memory, a bad device) takes the others
+// out with it instead of leaving them blocked in an all-gather it will never join.
+struct HostAgreement {
+    std::mutex m;
+    std::condition_variable cv;
+    int world = 1, arrived = 0, worst = LSDSORT_OK, agreed = LSDSORT_OK;
+    unsigned long long generation = 0;
+    int agree(int status)
+    {
+        std::unique_lock<std::mutex> lock(m);
+        if (status < worst) worst = status;
+        const unsigned long long gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            agreed = worst;
+            worst = LSDSORT_OK;
+            generation++;
+            cv.notify_all();
+        } else {
+            cv.wait(lock, [&] { return generation != gen; });
+        }
+        return agreed;
+    }
+};
+
 struct CommSet {
+    std::mutex busy;                 // one call at a time per set: the communicators, side streams and pinned buffers are shared
     std::vector<lsdsort_comm*> comms;
+    std::vector<int> devices;        // HIP device of each rank
+    HostAgreement agreement;
 };
 std::mutex g_sets_mutex;
-CommSet* g_sets[9] = {};   // by device count; made once, kept for the life of the process
+CommSet* g_sets[9] = {};        // by device count; made once, kept for the life of the process
+CommSet* g_loop_sets[9] = {};   // the loopback twins, on the device current at their creation
 
-int comm_set(int ndev, CommSet** out)
+int comm_set(int ndev, bool loopback, CommSet** out)
 {
     std::lock_guard<std::mutex> lock(g_sets_mutex);
-    if (g_sets[ndev]) {
-        *out = g_sets[ndev];
+    int cur = 0;
+    SH_HIP(hipGetDevice(&cur));
+    CommSet*& slot = loopback ? g_loop_sets[ndev] : g_sets[ndev];
+    if (slot && loopback && slot->devices[0] != cur) {   // the loopback set follows the current device
+        for (lsdsort_comm* c : slot->comms) (void)lsdsort_comm_destroy(c);
+        delete slot;
+        slot = nullptr;
+    }
+    if (slot) {
+        *out = slot;
         return LSDSORT_OK;
     }
-    if (!rccl().ok) return LSDSORT_ERR_UNSUPPORTED;
-    std::vector<ncclComm_t> raw(ndev);
-    std::vector<int> devs(ndev);
-    for (int i = 0; i < ndev; i++) devs[i] = i;
-    SH_NCCL(rccl().CommInitAll(raw.data(), ndev, devs.data()));
     CommSet* set = new CommSet;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    set->agreement.world = ndev;
     int status = LSDSORT_OK;
-    for (int i = 0; i < ndev && status == LSDSORT_OK; i++) {
-        lsdsort_comm* c = new lsdsort_comm;
-        c->comm = raw[i];
-        c->world = ndev;
-        c->rank = i;
-        set->comms.push_back(c);
-        if (hipSetDevice(i) != hipSuccess) status = LSDSORT_ERR_NO_DEVICE;
-        else status = finish_comm(c);
+    if (loopback) {
+        std::vector<lsdsort_comm*> raw(ndev, nullptr);
+        status = lsdsort_comm_create_loopback(ndev, raw.data());
+        if (status == LSDSORT_OK) {
+            set->comms = raw;
+            set->devices.assign(ndev, cur);
+        }
+    } else {
+        if (!rccl().ok) {
+            delete set;
+            return LSDSORT_ERR_UNSUPPORTED;
+        }
+        std::vector<ncclComm_t> raw(ndev);
+        std::vector<int> devs(ndev);
+        for (int i = 0; i < ndev; i++) devs[i] = i;
+        ncclResult_t r = rccl().CommInitAll(raw.data(), ndev, devs.data());
+        if (r != ncclSuccess) {
+            std::snprintf(t_comm_error, sizeof(t_comm_error), "ncclCommInitAll: %s", rccl().GetErrorString(r));
+            delete set;
+            return LSDSORT_ERR_COMM;
+        }
+        for (int i = 0; i < ndev; i++) {
+            lsdsort_comm* c = new lsdsort_comm;
+            RcclTransport* t = new RcclTransport;
+            t->comm = raw[i];
+            c->transport = t;
+            c->world = ndev;
+            c->rank = i;
+            set->comms.push_back(c);
+            set->devices.push_back(i);
+            if (status == LSDSORT_OK) {
+                if (hipSetDevice(i) != hipSuccess) status = LSDSORT_ERR_NO_DEVICE;
+                else status = finish_comm(c);
+            }
+        }
+        (void)hipSetDevice(cur);
     }
-    (void)hipSetDevice(prev);
     if (status != LSDSORT_OK) {
         for (lsdsort_comm* c : set->comms) (void)lsdsort_comm_destroy(c);
         delete set;
         return status;
     }
-    g_sets[ndev] = set;
+    slot = set;
     *out = set;
     return LSDSORT_OK;
 }
 
-int sort_shard(lsdsort_comm* c, uint32_t* keys, size_t n, size_t begin, size_t n_local, int radix_bits)
+// One rank's share of a call.  Phase A (local: device, buffers, upload) ends in an agreement of all ranks; only if every
+// rank is ready does anybody enter phase B (the collective step).  Capacity: a share plus a quarter first; if some rank
+// would receive more (skewed keys) every rank learns it together (LSDSORT_ERR_CAPACITY) and the step is repeated once with
+// exact sizes -- again behind an agreement, because the larger buffers are allocated locally.
+int sort_shard(CommSet* set, int rank, uint32_t* keys, size_t begin, size_t n_local, int radix_bits)
 {
-    SH_HIP(hipSetDevice(c->rank));
-    SH_TRY(lsdsort_prepare_device());
-    const size_t cap = n;   // any distribution: in the worst case every key belongs to one rank
-    const size_t ws_bytes = lsdsort_sharded_workspace_bytes(n_local, cap, c->world, radix_bits);
+    lsdsort_comm* c = set->comms[rank];
     uint32_t *d_in = nullptr, *d_out = nullptr;
     void* d_ws = nullptr;
-    auto body = [&]() -> int {
-        SH_HIP(hipMalloc(reinterpret_cast<void**>(&d_in), (n_local ? n_local : 1) * sizeof(uint32_t)));
-        SH_HIP(hipMalloc(reinterpret_cast<void**>(&d_out), cap * sizeof(uint32_t)));
+    hipStream_t stream = nullptr;   // this rank's own (virtual ranks share a device: the null stream would serialise them)
+    size_t cap = n_local + n_local / 4 + 4096, ws_bytes = 0;
+    if (cap > LSDSORT_MAX_KEYS) cap = LSDSORT_MAX_KEYS;
+    auto release = [&]() {
+        if (d_ws) (void)hipFree(d_ws);
+        if (d_out) (void)hipFree(d_out);
+        d_ws = nullptr;
+        d_out = nullptr;
+    };
+    auto reserve = [&]() -> int {
+        ws_bytes = lsdsort_sharded_workspace_bytes(n_local, cap, c->world, radix_bits);
+        if (ws_bytes == 0) return LSDSORT_ERR_TOO_LARGE;
+        SH_HIP(hipMalloc(reinterpret_cast<void**>(&d_out), (cap ? cap : 1) * sizeof(uint32_t)));
         SH_HIP(hipMalloc(&d_ws, ws_bytes));
-        if (n_local) SH_HIP(hipMemcpy(d_in, keys + begin, n_local * sizeof(uint32_t), hipMemcpyHostToDevice));
-        size_t n_out = 0;
-        uint64_t offset = 0;
-        SH_TRY(lsdsort_sharded_u32_device(c, d_in, n_local, d_out, cap, &n_out, &offset, nullptr, d_ws, ws_bytes, radix_bits, nullptr));
-        SH_TRY(lsdsort_sharded_check_device(d_ws, n_local, cap, c->world, radix_bits, nullptr));
-        // every rank's shard left the host before its sends were posted, and my receives needed everybody's sends:
-        // nothing of the input array is still unread when a slice comes back into it
-        if (n_out) SH_HIP(hipMemcpy(keys + offset, d_out, n_out * sizeof(uint32_t), hipMemcpyDeviceToHost));
         return LSDSORT_OK;
     };
-    const int status = body();
-    if (d_ws) (void)hipFree(d_ws);
-    if (d_out) (void)hipFree(d_out);
+    auto set_up = [&]() -> int {
+        SH_HIP(hipSetDevice(set->devices[rank]));
+        SH_TRY(lsdsort_prepare_device());
+        SH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        SH_HIP(hipMalloc(reinterpret_cast<void**>(&d_in), (n_local ? n_local : 1) * sizeof(uint32_t)));
+        if (n_local) SH_HIP(hipMemcpy(d_in, keys + begin, n_local * sizeof(uint32_t), hipMemcpyHostToDevice));
+        return reserve();
+    };
+    int status = set->agreement.agree(set_up());
+    size_t n_out = 0;
+    uint64_t offset = 0;
+    for (int attempt = 0; attempt < 2 && status == LSDSORT_OK; attempt++) {
+        status = lsdsort_sharded_u32_device(c, d_in, n_local, d_out, cap, &n_out, &offset, nullptr, d_ws, ws_bytes, radix_bits, stream);
+        if (status != LSDSORT_ERR_CAPACITY || attempt == 1) break;
+        // collective verdict: every rank is here.  Exact sizes, local allocation, agreement, once more.
+        (void)hipStreamSynchronize(stream);
+        release();
+        cap = n_out;
+        status = set->agreement.agree(reserve());
+    }
+    if (status == LSDSORT_OK) status = lsdsort_sharded_check_device(d_ws, n_local, cap, c->world, radix_bits, stream);
+    // every rank's shard left the host before its sends were posted, and my receives needed everybody's sends:
+    // nothing of the input array is still unread when a slice comes back into it
+    if (status == LSDSORT_OK && n_out && hipMemcpy(keys + offset, d_out, n_out * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        status = LSDSORT_ERR_HIP;
+    }
+    if (stream) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(stream);
+    }
+    release();
     if (d_in) (void)hipFree(d_in);
+    (void)hipGetLastError();
     return status;
 }
 }  // namespace
 
-int sort_host_multi(uint32_t* keys, size_t n, int radix_bits, int num_gpus)
+int sort_host_multi(uint32_t* keys, size_t n, int radix_bits, int num_gpus, bool loopback)
 {
     if (log2_world(num_gpus) < 1) return LSDSORT_ERR_INVALID_ARG;
     if (n > LSDSORT_MAX_KEYS) return LSDSORT_ERR_TOO_LARGE;
     if (lsdsort_workspace_bytes(1, radix_bits, 0) == 0) return LSDSORT_ERR_INVALID_ARG;
     if (n == 0) return LSDSORT_OK;
     if (!keys) return LSDSORT_ERR_INVALID_ARG;
-    if (lsdsort_device_count() < num_gpus) return LSDSORT_ERR_NO_DEVICE;
+    if (lsdsort_device_count() < (loopback ? 1 : num_gpus)) return LSDSORT_ERR_NO_DEVICE;
     int prev = 0;
     (void)hipGetDevice(&prev);
     CommSet* set = nullptr;
-    SH_TRY(comm_set(num_gpus, &set));
+    SH_TRY(comm_set(num_gpus, loopback, &set));
+    std::lock_guard<std::mutex> busy(set->busy);
     std::vector<int> status(num_gpus, LSDSORT_OK);
     std::vector<std::thread> threads;
     const size_t per = n / num_gpus, rem = n % num_gpus;
     size_t begin = 0;
     for (int i = 0; i < num_gpus; i++) {
         const size_t n_local = per + ((size_t)i < rem ? 1 : 0);
-        threads.emplace_back([&, i, begin, n_local] { status[i] = sort_shard(set->comms[i], keys, n, begin, n_local, radix_bits); });
+        threads.emplace_back([&, i, begin, n_local] { status[i] = sort_shard(set, i, keys, begin, n_local, radix_bits); });
         begin += n_local;
     }
     for (std::thread& t : threads) t.join();

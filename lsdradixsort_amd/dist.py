@@ -112,15 +112,34 @@ class ShardedSorter:
         self.rank = dist.get_rank(group) if live else 0
         _log2_exact(self.world)
         L = api.lib()
+        # Rank 0 makes the RCCL id; EVERY rank takes part in the broadcast whatever happened on rank 0: the message carries a
+        # status byte in front of the 128 id bytes (zeros on failure), and every rank raises AFTER it if the status is bad.  So
+        # all ranks always run the same sequence of collectives (a rank-0 failure used to leave the others alone in the
+        # broadcast while rank 0 went on to the caller's next collective: ADVICE r2).
         ident = (ctypes.c_ubyte * 128)()
+        id_status = 0
         if self.rank == 0:
-            check(L.lsdsort_comm_unique_id(ident), "lsdsort_comm_unique_id")
+            id_status = int(L.lsdsort_comm_unique_id(ident))
+            if id_status != 0:
+                ident = (ctypes.c_ubyte * 128)()
         if self.world > 1:
             on_gpu = dist.get_backend(group) == "nccl"
-            t = torch.tensor(list(ident), dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
+            payload = [id_status & 0xFF] + list(ident)
+            t = torch.tensor(payload, dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
             dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            ident = (ctypes.c_ubyte * 128)(*[int(x) for x in t.cpu()])
+            got = [int(x) for x in t.cpu()]
+            id_status = got[0] - 256 if got[0] > 127 else got[0]
+            ident = (ctypes.c_ubyte * 128)(*got[1:])
+        check(id_status, "lsdsort_comm_unique_id (rank 0)")
         handle = ctypes.c_void_p()
+        # ncclCommInitRank is itself collective: a rank that cannot even try (library refuses locally) must be known to all
+        # before the others enter it -- a second tiny agreement over torch.distributed when there is more than one rank
+        local = int(L.lsdsort_prepare_device())
+        if self.world > 1:
+            t = torch.tensor([local], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            local = int(t.item())
+        check(local, "lsdsort_prepare_device (some rank)")
         check(L.lsdsort_comm_create(ident, self.world, self.rank, ctypes.byref(handle)), "lsdsort_comm_create")
         self._comm = handle
         self._ws = None
@@ -169,7 +188,7 @@ class ShardedSorter:
             st = L.lsdsort_sharded_u32_device_ex(self._comm, local_keys.data_ptr(), n_local, out.data_ptr(), cap, ctypes.byref(n_out),
                                                  ctypes.byref(offset), matrix, ws.data_ptr(), ws.numel(), self.radix_bits,
                                                  self.PARTITIONS[self.partition], stream)
-            if st == -5 and attempt == 0:            # LSDSORT_ERR_TOO_LARGE on EVERY rank (skewed keys): exact sizes this time
+            if st == -9 and attempt == 0:            # LSDSORT_ERR_CAPACITY: collective, EVERY rank got it (skewed keys): exact sizes this time
                 cap = max(int(n_out.value), 1)
                 continue
             self._check(st, "lsdsort_sharded_u32_device")
@@ -266,3 +285,89 @@ def distributed_sort(local_keys, backend=None, group=None, exchange_always: bool
     backend.sort_inplace(received)
     offset = int(matrix_host[:, :rank].sum())
     return ShardResult(received, offset, matrix_host)
+
+
+class LoopbackWorld:
+    """``world`` VIRTUAL ranks of the C++ sharded step on the current device (``lsdsort_comm_create_loopback``): the same
+    step as over RCCL -- partition, count exchange, capacity verdict, grouped exchange, local sort -- with device copies for
+    the fabric, so a one-GPU machine runs it with world > 1.  Each rank is driven by its own host thread on its own stream
+    (the step is collective).  ``step`` returns, per rank, ``(status, ShardResult | None, n_out)``."""
+
+    PARTITIONS = ShardedSorter.PARTITIONS
+
+    def __init__(self, world: int, radix_bits: int = 8):
+        import ctypes
+
+        from . import api
+        from .errors import check
+
+        self._api = api
+        _log2_exact(world)
+        self.world = world
+        self.radix_bits = radix_bits
+        handles = (ctypes.c_void_p * world)()
+        check(api.lib().lsdsort_comm_create_loopback(world, handles), "lsdsort_comm_create_loopback")
+        self._comms = [ctypes.c_void_p(h) for h in handles]
+        self.last = [None] * world      # (workspace tensor, n_local, capacity) of each rank's last step
+
+    def close(self):
+        for c in getattr(self, "_comms", []):
+            self._api.lib().lsdsort_comm_destroy(c)
+        self._comms = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def step(self, shards, capacities=None, partition: str = "msb", workspace_bytes=None, timeout: float = 120.0):
+        """One collective step: ``shards[r]`` is rank r's int32 CUDA tensor (left untouched), ``capacities[r]`` its output
+        capacity (default: everything, so that nothing can overflow).  ``workspace_bytes[r]`` overrides rank r's workspace
+        size (tests use a too-small one to make a rank fail on its own)."""
+        import ctypes
+        import threading
+
+        import torch
+
+        L = self._api.lib()
+        W = self.world
+        total = sum(int(s.numel()) for s in shards)
+        caps = list(capacities) if capacities is not None else [total] * W
+        results = [None] * W
+        device = torch.cuda.current_device()
+
+        def run(r):
+            torch.cuda.set_device(device)
+            n_local = int(shards[r].numel())
+            need = int(L.lsdsort_sharded_workspace_bytes(n_local, caps[r], W, self.radix_bits))
+            given = need if workspace_bytes is None or workspace_bytes[r] is None else int(workspace_bytes[r])
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                ws = torch.empty(max(given, 256), dtype=torch.uint8, device="cuda")
+                out = torch.empty(max(caps[r], 1), dtype=torch.int32, device="cuda")
+            n_out = ctypes.c_size_t(0)
+            offset = ctypes.c_uint64(0)
+            matrix = (ctypes.c_uint64 * (W * W))()
+            st = L.lsdsort_sharded_u32_device_ex(self._comms[r], shards[r].data_ptr(), n_local, out.data_ptr(), caps[r], ctypes.byref(n_out),
+                                                 ctypes.byref(offset), matrix, ws.data_ptr(), given, self.radix_bits,
+                                                 self.PARTITIONS[partition], stream.cuda_stream)
+            res = None
+            if st == 0:
+                fault = int(L.lsdsort_sharded_check_device(ws.data_ptr(), n_local, caps[r], W, self.radix_bits, stream.cuda_stream))
+                if fault != 0:
+                    st = fault
+                else:
+                    counts = torch.tensor(list(matrix), dtype=torch.int64).view(W, W)
+                    res = ShardResult(out[: n_out.value], int(offset.value), counts)
+            stream.synchronize()
+            results[r] = (int(st), res, int(n_out.value))
+
+        threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(W)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout)
+            if t.is_alive():
+                raise TimeoutError("a virtual rank is still inside the step: a collective hang")
+        return results

@@ -10,6 +10,7 @@ LSDSORT_ERR_TOO_LARGE = -5
 LSDSORT_ERR_UNSUPPORTED = -6
 LSDSORT_ERR_DEVICE_FAULT = -7
 LSDSORT_ERR_COMM = -8
+LSDSORT_ERR_CAPACITY = -9
 
 LSDSORT_ALGO_ONESWEEP = 0
 LSDSORT_ALGO_STAGED = 1

@@ -59,7 +59,7 @@ int main()
             const int st = lsdsort_sharded_u32_device(raw, d_in, n, d_out, n - 1, &n_out, &off, nullptr, d_ws, ws_bytes, 8, stream);
             HIP_OK(hipStreamSynchronize(stream));
             lsdsort_comm_destroy(raw);
-            if (st != LSDSORT_ERR_TOO_LARGE || n_out != n) { std::fprintf(stderr, "expected LSDSORT_ERR_TOO_LARGE, got %d\n", st); return 1; }
+            if (st != LSDSORT_ERR_CAPACITY || n_out != n) { std::fprintf(stderr, "expected LSDSORT_ERR_CAPACITY, got %d\n", st); return 1; }
         }
         // the one-process form: more GPUs than this box has is an error, not a hang
         {

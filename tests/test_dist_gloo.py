@@ -94,3 +94,25 @@ def test_world_size_must_be_power_of_two():
     for bad in (0, 3, 6, 16):
         with pytest.raises(ValueError):
             _log2_exact(bad)
+
+
+@pytest.mark.parametrize("mode", ["id_fails", "no_device"])
+def test_sharded_sorter_setup_failure_is_seen_by_every_rank(tmp_path, mode):
+    """ShardedSorter's collective set-up when it cannot succeed: rank 0's id call fails (id_fails: -6 on every rank, AFTER
+    the broadcast all of them take part in), or no rank has a gfx950 device (no_device: this container; -2 everywhere, agreed
+    through an all_reduce in front of the collective ncclCommInitRank).  Either way every rank raises the same status and
+    the next collective of the caller still lines up (rank 0 raised before the broadcast and went on alone)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a usable GPU (on a GPU box the set-up would go on into ncclCommInitRank)")
+    world = 2
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_sharded_init_worker.py"), str(r), str(world), port,
+                               str(tmp_path), mode]) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=180) == 0
+    outs = [open(tmp_path / f"out_{r}.txt").read().split(",") for r in range(world)]
+    expect = "-6" if mode == "id_fails" else "-2"
+    assert [o[0] for o in outs] == [expect] * world, outs
+    assert [o[1] for o in outs] == ["3"] * world, outs      # 1 + 2: the all_reduce behind the failed set-up matched up

@@ -562,7 +562,7 @@ def test_cpp_sharded_step_world_of_one(gpu, oracle_mod):
             assert np.array_equal(gpu.to_host(res.keys), np.sort(keys)), n
             assert np.array_equal(gpu.to_host(d), keys), "the input shard is left untouched"
             assert sorter.check_fault() == 0
-        # a capacity that is too small: every rank hears LSDSORT_ERR_TOO_LARGE before the exchange; the face retries once
+        # a capacity that is too small: every rank hears LSDSORT_ERR_CAPACITY before the exchange; the face retries once
         keys = oracle_mod.mt19937_keys((1 << 20) + 9, 10)
         res = sorter.sort(gpu.to_device(keys), capacity=1000)
         assert np.array_equal(gpu.to_host(res.keys), np.sort(keys))
