@@ -98,7 +98,8 @@ LSDSORT_API int lsdsort_pairs_u32(uint32_t* keys, uint32_t* vals, size_t n);
  * concurrently from different host threads and on different streams; two calls sharing a workspace must be
  * ordered by the caller (same stream, or an event).  The tuning setters (lsdsort_set_*) are process-wide. */
 
-/* Bytes of device workspace the device entries need for (n, radix_bits, pairs?, algorithm).
+/* Bytes of device workspace the device entries need for (n, radix_bits, pairs, algorithm); `pairs` = the number of 32-bit
+ * payload arrays that travel with the keys: 0 keys only, 1 key/value pairs, 2 or 3 for lsdsort_multi_u32_device.
  * Replaces the reference's d_b + d_h + d_block_sums sizing, .cu:919-930 and
  * GetGPUPrefixSumBlockSumsCount .cu:265-276.  Returns 0 for invalid arguments.  The figure is
  * monotonic in n and covers every tile shape the library may pick for up to n keys: a workspace
@@ -116,6 +117,12 @@ LSDSORT_API int lsdsort_u32_device(uint32_t* d_keys, void* d_workspace, size_t w
 LSDSORT_API int lsdsort_pairs_u32_device(uint32_t* d_keys, uint32_t* d_vals, void* d_workspace,
                                          size_t workspace_bytes, size_t n, int radix_bits,
                                          void* hip_stream);
+/* Keys with up to THREE 32-bit payload arrays (d_vals[0 .. num_vals-1], num_vals 1..3), each permuted exactly like the
+ * keys, stable: the building block of the record sorts below (a 64-bit payload = two arrays; the other word of a 64-bit
+ * key = one more).  The key/value kernel sends the arrays through the same LDS slots one after the other: 8 + 8 num_vals
+ * bytes per key per pass.  Workspace: lsdsort_workspace_bytes(n, radix_bits, num_vals).  No reference counterpart (.cu:62). */
+LSDSORT_API int lsdsort_multi_u32_device(uint32_t* d_keys, uint32_t* const* d_vals, int num_vals, void* d_workspace,
+                                         size_t workspace_bytes, size_t n, int radix_bits, void* hip_stream);
 /* Same with the pass structure chosen explicitly; d_vals may be NULL (keys only). */
 LSDSORT_API int lsdsort_u32_device_ex(uint32_t* d_keys, uint32_t* d_vals, void* d_workspace,
                                       size_t workspace_bytes, size_t n, int radix_bits,
@@ -137,8 +144,8 @@ LSDSORT_API int lsdsort_keys_device(void* d_keys, uint32_t* d_vals, void* d_work
  *   lsdsort_u64_device     : uint64 keys only.  Split into words, two key/value sorts (each word once the key,
  *                            once the payload), merge: 8 passes at radix 8, 16 B/key/pass.
  *   lsdsort_records_device : keys of key_bits (32 | 64) with payloads of val_bits (32 | 64; 32/32 is
- *                            lsdsort_pairs_u32_device), stable by key: an index rides through the sorts and the
- *                            records are gathered once at the end.
+ *                            lsdsort_pairs_u32_device), stable by key: every word that is not the key word being sorted on
+ *                            rides through the passes as a payload array of its own (lsdsort_multi_u32_device); no gather.
  * lsdsort_wide_workspace_bytes(n, radix_bits, key_bits, val_bits) sizes the workspace (val_bits 0 = keys only);
  * lsdsort_wide_check_device reads the fault word of the sorts inside it (like lsdsort_check_device). */
 LSDSORT_API size_t lsdsort_wide_workspace_bytes(size_t n, int radix_bits, int key_bits, int val_bits);

@@ -9,8 +9,28 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# LSDSORT_LIB lets diagnostic tools load an instrumented build; the package default is the product.
-LIB_PATH = os.environ.get("LSDSORT_LIB") or os.path.join(_HERE, "liblsdsort.so")
+PRODUCT_LIB = os.path.join(_HERE, "liblsdsort.so")
+
+
+def _library_path() -> str:
+    """The product library, always -- except for the in-tree DIAGNOSTIC and A/B builds of this very source tree
+    (``make faultinject | stats | variant`` write ``liblsdsort_<tag>.so`` next to the product): tests/test_fault_path.py and
+    tools/ab_bench.sh select one with ``LSDSORT_LIB``.  Anything else in that variable -- another directory, another name --
+    is refused loudly: an environment variable must not be able to put a foreign library behind this package."""
+    want = os.environ.get("LSDSORT_LIB")
+    if not want:
+        return PRODUCT_LIB
+    real = os.path.realpath(want)
+    name = os.path.basename(real)
+    if real == os.path.realpath(PRODUCT_LIB):
+        return PRODUCT_LIB
+    if os.path.dirname(real) != os.path.realpath(_HERE) or not (name.startswith("liblsdsort_") and name.endswith(".so")):
+        raise ImportError(f"LSDSORT_LIB={want!r} is not an in-tree diagnostic build ({_HERE}/liblsdsort_<tag>.so); "
+                          "unset it to use the product library")
+    return real
+
+
+LIB_PATH = _library_path()
 
 c_u32p = ctypes.c_void_p   # device or host addresses are passed as integers
 c_size = ctypes.c_size_t
@@ -46,6 +66,7 @@ SIGNATURES = {
     "lsdsort_u32_device": (c_int, [c_u32p, ctypes.c_void_p, c_size, c_size, c_int, ctypes.c_void_p]),
     "lsdsort_pairs_u32_device": (c_int, [c_u32p, c_u32p, ctypes.c_void_p, c_size, c_size, c_int, ctypes.c_void_p]),
     "lsdsort_u32_device_ex": (c_int, [c_u32p, c_u32p, ctypes.c_void_p, c_size, c_size, c_int, c_int, ctypes.c_void_p]),
+    "lsdsort_multi_u32_device": (c_int, [c_u32p, ctypes.POINTER(ctypes.c_void_p), c_int, ctypes.c_void_p, c_size, c_size, c_int, ctypes.c_void_p]),
     "lsdsort_keys_device": (c_int, [ctypes.c_void_p, c_u32p, ctypes.c_void_p, c_size, c_size, c_int, c_int, c_int, ctypes.c_void_p]),
     "lsdsort_wide_workspace_bytes": (c_size, [c_size, c_int, c_int, c_int]),
     "lsdsort_u64_device": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_size, c_size, c_int, ctypes.c_void_p]),

@@ -19,7 +19,7 @@ from .errors import LSDSORT_ALGO_ONESWEEP, LSDSORT_ALGO_STAGED, check
 __all__ = [
     "sort", "sort_pairs", "to_device", "to_host", "workspace_bytes", "GPULSDRadixSort",
     "GPULSDRadixSortTimed", "BuildHistograms", "BuildOffsets", "RankScatter", "DigitHistograms",
-    "MSBPartition", "SplitterPartition", "GPUSortTyped", "GPUSortWide", "tile_keys", "set_tile_config", "set_rank_method", "rank_method", "set_xcd_chunk", "LSDSORT_ALGO_ONESWEEP", "LSDSORT_ALGO_STAGED",
+    "MSBPartition", "SplitterPartition", "GPUSortTyped", "GPUSortWide", "GPUSortMulti", "tile_keys", "set_tile_config", "set_rank_method", "rank_method", "set_xcd_chunk", "LSDSORT_ALGO_ONESWEEP", "LSDSORT_ALGO_STAGED",
 ]
 
 
@@ -156,6 +156,36 @@ def GPULSDRadixSort(d_keys, r: int = 8, d_vals=None, algorithm: int = LSDSORT_AL
     if check_fault and n:
         check(lib().lsdsort_check_device(workspace.data_ptr(), _stream(stream)), "lsdsort_check_device")
     return d_keys if not pairs else (d_keys, d_vals)
+
+
+def GPUSortMulti(d_keys, payloads, r: int = 8, workspace=None, stream=None, check_fault: bool = False):
+    """Keys with one to three 32-bit payload arrays (``lsdsort_multi_u32_device``): every array in ``payloads`` (int32 CUDA
+    tensors as long as ``d_keys``) is permuted exactly like the keys, stable by key.  In place."""
+    import ctypes
+
+    _dev_i32(d_keys, "d_keys")
+    n = d_keys.numel()
+    payloads = list(payloads)
+    if not 1 <= len(payloads) <= 3:
+        raise ValueError("one to three payload arrays")
+    for i, v in enumerate(payloads):
+        _dev_i32(v, f"payloads[{i}]")
+        if v.numel() != n:
+            raise ValueError("keys and payloads differ in length")
+    if workspace is None:
+        need = int(lib().lsdsort_workspace_bytes(n, r, len(payloads)))
+        torch = _torch()
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=d_keys.device)
+        else:
+            workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=d_keys.device)
+    ptrs = (ctypes.c_void_p * len(payloads))(*[v.data_ptr() for v in payloads])
+    check(lib().lsdsort_multi_u32_device(d_keys.data_ptr(), ptrs, len(payloads), workspace.data_ptr(), workspace.numel(), n, r,
+                                         _stream(stream)), "lsdsort_multi_u32_device")
+    if check_fault and n:
+        check(lib().lsdsort_check_device(workspace.data_ptr(), _stream(stream)), "lsdsort_check_device")
+    return d_keys, payloads
 
 
 _KEY_TYPES = {"uint32": 0, "int32": 1, "float32": 2}

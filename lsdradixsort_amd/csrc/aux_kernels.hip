@@ -365,7 +365,9 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
     const uint4* __restrict__ keys4 = reinterpret_cast<const uint4*>(keys);
     const uint32_t full_chunks = vec_chunks / VPT * VPT;
     auto load_group = [&](uint32_t c, uint4 (&v)[VPT]) {
-#ifdef LSD_HIST_NT_LOADS   // non-temporal loads: a read-only stream of them runs 8 % faster than plain loads (profiles/r3_ceilings.txt)
+#ifndef LSD_HIST_PLAIN_LOADS   // non-temporal loads: a read-only stream of them runs 8 % faster than plain ones (profiles/r3_ceilings.txt:
+                             // 5.67-5.88 against 5.24-5.40 TB/s), and the keys are not read again before 2 GiB of other traffic has
+                             // gone by; stage 1 0.267-0.274 -> 0.249 ms at 2^28 keys (tools/ab_bench.sh); -DLSD_HIST_PLAIN_LOADS builds the other
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const u32x4* __restrict__ k4 = reinterpret_cast<const u32x4*>(keys);
 #pragma unroll
@@ -378,6 +380,8 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
         for (int u = 0; u < VPT; u++) v[u] = keys4[(size_t)(c + u) * THREADS + tid];
 #endif
     };
+    uint32_t key1 = 0, key2 = 0;        // heavy-key candidates of this wave (uniform; kept from group to group)
+    bool have1 = false, have2 = false;
     // region_of(u): pass-0 region of vector u of the group (a vector's 4 keys, and the 256 keys of the wave's row, share it)
     auto count_vectors = [&](auto region_of, uint4 (&v)[DMA ? joint_dma_vpt<R, WIDE>() : VPT]) {
         constexpr int NV = DMA ? joint_dma_vpt<R, WIDE>() : VPT;
@@ -388,6 +392,70 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
         }
         // region0_keys is a multiple of the chunk (THREADS*4 keys), so a chunk is in one region
         const uint32_t region_first = region_of(0);
+        // Heavy KEYS first (zeros, a default value, two-valued keys): a key equal to a candidate is counted for ALL its fields
+        // by one compare, ballot and population count -- against NF times that in the per-field form below, which such keys
+        // used to take (round 2: stage 1 at 4-bit digits 1.05 ms on half-zero keys against 0.25 ms on uniform ones).  The
+        // candidates are sticky across groups (a global default value stays one): the group's first keys are compared with
+        // them, and only if they do not describe the group (fewer than 16 lanes) is lane 0's key, then lane 32's, tried.
+        {
+            const uint32_t k0 = v[0].x;
+            uint32_t n1 = (uint32_t)__builtin_popcountll(__ballot(k0 == key1));
+            if (!have1 || n1 < kHeavyLanes) {
+                have1 = have2 = false;
+                const uint32_t a = __builtin_amdgcn_readfirstlane(k0);
+                unsigned long long m = __ballot(k0 == a);
+                if ((uint32_t)__builtin_popcountll(m) >= kHeavyLanes) {
+                    key1 = a;
+                    have1 = true;
+                } else {
+                    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)k0, 32);
+                    m = __ballot(k0 == b);
+                    if ((uint32_t)__builtin_popcountll(m) >= kHeavyLanes) {
+                        key1 = b;
+                        have1 = true;
+                    }
+                }
+                if (have1 && ~m != 0ull) {   // a second one: the first value that differs, if eight lanes hold it
+                    const uint32_t other = (uint32_t)__builtin_amdgcn_readlane((int)k0, (int)__builtin_ctzll(~m));
+                    if ((uint32_t)__builtin_popcountll(__ballot(k0 == other)) >= 8u) {
+                        key2 = other;
+                        have2 = true;
+                    }
+                }
+            }
+        }
+        if (have1) {
+            const uint32_t lane = tid & 63u;
+            uint32_t total1 = 0, total2 = 0;   // uniform: scalar registers
+#pragma unroll
+            for (int u = 0; u < NV; u++) {
+                const uint32_t region0 = region_of(u);
+                const uint32_t k4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                uint32_t n1 = 0, n2 = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const bool h1 = k4[q] == key1, h2 = have2 && k4[q] == key2;
+                    n1 += (uint32_t)__builtin_popcountll(__ballot(h1));
+                    n2 += (uint32_t)__builtin_popcountll(__ballot(h2));
+                    if (!(h1 || h2)) count_key_plain(k4[q], region0);
+                }
+                // field 0 carries the position region of the vector; the other fields are the key's alone
+                if (lane == 0) {
+                    if (n1) atomicAdd(&word(slot_of(0, key1, region0)), n1);
+                    if (n2) atomicAdd(&word(slot_of(0, key2, region0)), n2);
+                }
+                total1 += n1;
+                total2 += n2;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int f = 1; f < NF; f++) {
+                    if (total1) atomicAdd(&word(slot_of(f, key1, 0u)), total1);
+                    if (total2) atomicAdd(&word(slot_of(f, key2, 0u)), total2);
+                }
+            }
+            return;
+        }
         bool any = false;
 #pragma unroll
         for (int f = 0; f < NF; f++) {
@@ -647,17 +715,29 @@ __global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __res
     __shared__ uint32_t s_const[kPlanWords];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const int pass = blockIdx.x;
+    // This kernel is latency, not work: a small sort spends 5 of its 50 us here (rocprofv3, 2^20 keys, round 3).  So every
+    // global load it needs is requested up front, in one window: this pass's counts first ...
+    const uint32_t* c = counts + (size_t)pass * bins * REG;
+    uint32_t* table = tables + (size_t)pass * table_words;
+    uint32_t per_region[REG];
+    uint32_t total = 0;
+    if (tid < (uint32_t)bins) {
+#pragma unroll
+        for (int x = 0; x < REG; x++) per_region[x] = c[tid * REG + x];
+    }
     if (plan) {
-        // The pass plan (PassParams::plan): a digit that is the same for every key (one bin holds all n) makes its pass
-        // the identity.  This workgroup looks at its own pass and at the ones before it, whose number of REAL passes says
-        // which buffer its keys are in.
+        // ... then the pass plan (PassParams::plan): a digit that is the same for every key (one bin holds all n) makes its
+        // pass the identity.  This workgroup looks at its own pass and at the ones before it, whose number of REAL passes says
+        // which buffer its keys are in: (pass + 1) * bins (pass, digit) cells, dealt over the threads.
         if (tid < (uint32_t)kPlanWords) s_const[tid] = 0;
         __syncthreads();
-        for (int q = 0; q <= pass; q++) {
+        const uint32_t cells = (uint32_t)(pass + 1) * (uint32_t)bins;
+#pragma unroll 4
+        for (uint32_t cell = tid; cell < cells; cell += 256u) {
             uint32_t t = 0;
-            if (tid < (uint32_t)bins)
-                for (int x = 0; x < REG; x++) t += counts[(size_t)q * bins * REG + tid * REG + x];
-            if (tid < (uint32_t)bins && t == n) s_const[q] = 1;
+#pragma unroll
+            for (int x = 0; x < REG; x++) t += counts[(size_t)cell * REG + x];
+            if (t == n) s_const[cell / (uint32_t)bins] = 1;
         }
         __syncthreads();
         if (tid == 0) {
@@ -668,16 +748,9 @@ __global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __res
             if (pass + 1 == passes) plan[2 * passes] = (moved + (s_const[pass] ? 0u : 1u)) & 1u;
         }
     }
-    const uint32_t* c = counts + (size_t)pass * bins * REG;
-    uint32_t* table = tables + (size_t)pass * table_words;
-    uint32_t per_region[REG];
-    uint32_t total = 0;
     if (tid < (uint32_t)bins) {
 #pragma unroll
-        for (int x = 0; x < REG; x++) {
-            per_region[x] = c[tid * REG + x];
-            total += per_region[x];
-        }
+        for (int x = 0; x < REG; x++) total += per_region[x];
     }
     uint32_t incl = wave_inclusive_scan(total, lane);
     if (lane == 63u) s_wave[wave] = incl;
@@ -699,41 +772,33 @@ __global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __res
     }
     if (tid == 0) s_base[bins] = n;
     __syncthreads();
-    // Extents.  Written by one thread: eight entries and their running tile offset.
-    if (tid == 0) {
-        auto write_extents = [&](uint32_t* t, auto start_of) {
-            uint32_t off = 0;
-            for (int x = 0; x < REG; x++) {
-                uint32_t lo = start_of(x), hi = start_of(x + 1);
-                lo = lo < n ? lo : n;
-                hi = hi < n ? hi : n;
-                const uint32_t len = hi > lo ? hi - lo : 0u;
-                const uint32_t tiles = (len + tile_keys - 1) / tile_keys;
-                t[x] = lo;
-                t[kMaxRegions + x] = len;
-                t[2 * kMaxRegions + x] = tiles;
-                t[3 * kMaxRegions + x] = off;
-                off += tiles;
+    // Extents: lane x of the first wave owns region x; the regions' first status rows are an exclusive scan of their tile
+    // counts across those lanes.
+    if (wave == 0) {
+        auto write_extents = [&](uint32_t* t, uint32_t lo, uint32_t hi) {
+            lo = lo < n ? lo : n;
+            hi = hi < n ? hi : n;
+            const uint32_t len = hi > lo ? hi - lo : 0u;
+            const uint32_t tiles = lane < (uint32_t)REG ? (len + tile_keys - 1) / tile_keys : 0u;
+            const uint32_t upto = wave_inclusive_scan(tiles, lane);
+            if (lane < (uint32_t)REG) {
+                t[lane] = lo;
+                t[kMaxRegions + lane] = len;
+                t[2 * kMaxRegions + lane] = tiles;
+                t[3 * kMaxRegions + lane] = upto - tiles;
             }
         };
+        const uint32_t x = lane < (uint32_t)REG ? lane : 0u;
         if (pass == 0) {
-            if (REG == 1) {
-                write_extents(table, [&](int x) { return x == 0 ? 0u : n; });
-            } else {
-                write_extents(table, [&](int x) {
-                    const unsigned long long e = (unsigned long long)x * region0_keys;
-                    return e < n ? (uint32_t)e : n;
-                });
-            }
+            const unsigned long long e0 = (unsigned long long)x * region0_keys, e1 = e0 + region0_keys;
+            if (REG == 1) write_extents(table, 0u, n);
+            else write_extents(table, e0 < n ? (uint32_t)e0 : n, e1 < n ? (uint32_t)e1 : n);
         }
         if (pass + 1 < passes) {
             uint32_t* next = tables + (size_t)(pass + 1) * table_words;
-            if (REG == 1) {
-                write_extents(next, [&](int x) { return x == 0 ? 0u : n; });
-            } else {
-                const int per = bins / REG;   // digits per region
-                write_extents(next, [&](int x) { return s_base[x * per]; });
-            }
+            const int per = bins / REG;   // digits per region
+            if (REG == 1) write_extents(next, 0u, n);
+            else write_extents(next, s_base[x * per], s_base[(x + 1) * per]);
         }
     }
 }
@@ -1095,6 +1160,15 @@ hipError_t launch_rank_scatter_small(int radix_bits, int shape_id, int rank_meth
 static const TileShape kShapesR8[] = {{512, 32}, {1024, 16}, {1024, 32}, {512, 16}, {1024, 32}, {256, 16}};
 static const TileShape kShapesR4[] = {{512, 32}, {512, 16}, {256, 16}, {1024, 32}, {1024, 32}, {1024, 16}};
 static const TileShape kShapesSmall[] = {{256, 16}, {512, 32}, {1024, 32}};
+
+bool single_round_shape(int radix_bits, int id)
+{
+    // the CAP arguments of rank_scatter_r8.hip / _r4.hip / _small.hip: r8 shapes 1 (1024 x 16, CAP 8192) and 2 (1024 x 32,
+    // CAP 16384) and r4 shape 3 (1024 x 32, CAP 16384) reorder in two rounds
+    if (radix_bits == 8) return id != 1 && id != 2;
+    if (radix_bits == 4) return id != 3;
+    return true;
+}
 
 int tile_shapes(int radix_bits, const TileShape** out)
 {

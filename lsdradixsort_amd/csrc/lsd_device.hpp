@@ -18,11 +18,13 @@ typedef __attribute__((address_space(3))) uint64_t lds_u64;
 // ---- tile-status words of the chained scan --------------------------------------------
 // One 32-bit word carries value and state together, so a single relaxed agent-scope store
 // publishes it and a single relaxed agent-scope load observes it (no fences: the data is the
-// flag).  The 2-bit code alternates meaning with the parity of the pass so ONE status array
-// serves every pass of a sort without re-zeroing: at the start of pass p every word still
-// holds pass p-1's final state, which reads as "not written yet" for pass p.
-//   even pass: 1 = tile aggregate, 2 = inclusive prefix, 0 = stale
-//   odd  pass: 3 = tile aggregate, 0 = inclusive prefix, 2 = stale
+// flag).  State = the low two bits:  0 = stale (not written in this pass), 1 = tile aggregate,
+// 2 = inclusive prefix.  A sort keeps TWO status arrays: a pass works in one while its workgroups
+// zero the other for the pass after it (rank_scatter.hpp, clear_next; the sort's opening memset
+// covers the first), so every word a pass reads is either zero or was written by THAT pass -- no
+// word outlives its pass (a single never-cleared, parity-coded array is
+// what let round 1's prototype read an old prefix as a current one).  The codes still take a
+// `parity` argument from that scheme; every launch passes 0.
 __device__ __forceinline__ constexpr uint32_t code_aggregate(uint32_t parity) { return parity ? 3u : 1u; }
 __device__ __forceinline__ constexpr uint32_t code_prefix(uint32_t parity) { return parity ? 0u : 2u; }
 __device__ __forceinline__ constexpr uint32_t code_stale(uint32_t parity) { return parity ? 2u : 0u; }

@@ -19,6 +19,8 @@ struct TileShape {
 
 // Compiled tile shapes for a radix; index 0 is the default.  Returns the count.
 int tile_shapes(int radix_bits, const TileShape** out);
+// Does shape `id` reorder its whole tile in ONE LDS round (CAP == tile)?  Further payload arrays need that.
+bool single_round_shape(int radix_bits, int id);
 
 // Regions.  A pass's input is split into contiguous regions whose digit histograms are known
 // before the pass starts, so each region carries its own chained scan over its own tiles and no
@@ -87,6 +89,12 @@ struct PassParams {
     uint32_t* out;
     const uint32_t* vals_in;   // null: keys only
     uint32_t* vals_out;
+    // Further payload arrays (records: a 64-bit payload's second word, the other word of a 64-bit key -- wide.hip): the key/value
+    // kernel sends each through the same LDS slots and destinations as the first, one after the other; num_payloads = 1 + the
+    // number of these that are set (0 or 1 = the ordinary keys / pairs launch).  Single-round tile shapes only.
+    const uint32_t* more_in[2];
+    uint32_t* more_out[2];
+    uint32_t num_payloads;
     // Chained form only, may be null.  plan[0] != 0: this pass's digit is the same for every key -- the pass is the
     // identity and is skipped (its workgroups only clear the next pass's status rows).  plan[1] != 0: an odd number of
     // passes before this one really ran, so the keys are in `out` and go to `in` (the roles swap).  Written by stage 2

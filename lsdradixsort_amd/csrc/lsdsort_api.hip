@@ -122,6 +122,7 @@ struct Layout {
     size_t scratch = 0;      // staged: strip sums
     size_t alt_keys = 0;
     size_t alt_vals = 0;
+    size_t alt_more[2] = {0, 0};   // further payload arrays (records: lsdsort_multi_u32_device)
     size_t total = 0;
     uint32_t tiles = 0;      // ceil(n / tile)
     uint32_t rows = 0;       // onesweep: status rows = grid size = tiles + one ragged tile per region
@@ -129,8 +130,10 @@ struct Layout {
     int regions = 1;
 };
 
-Layout make_layout(size_t n, int radix_bits, bool pairs, int algorithm, const TileShape& shape)
+// payloads: number of 32-bit payload arrays that travel with the keys (0 = keys only, 1 = pairs, up to 3)
+Layout make_layout(size_t n, int radix_bits, int payloads, int algorithm, const TileShape& shape)
 {
+    const bool pairs = payloads > 0;
     Layout L;
     const size_t bins = (size_t)1 << radix_bits;
     const size_t tile = (size_t)shape.tile();
@@ -167,6 +170,10 @@ Layout make_layout(size_t n, int radix_bits, bool pairs, int algorithm, const Ti
     off = align_up(off + n * sizeof(uint32_t));
     if (pairs) {
         L.alt_vals = off;
+        off = align_up(off + n * sizeof(uint32_t));
+    }
+    for (int e = 0; e + 1 < payloads && e < 2; e++) {
+        L.alt_more[e] = off;
         off = align_up(off + n * sizeof(uint32_t));
     }
     L.total = off;
@@ -225,6 +232,7 @@ std::atomic<uint32_t> g_xcd_chunk{16};   // consecutive tiles kept on one XCD
 std::atomic<unsigned long long*> g_stats{nullptr};   // diagnostic builds only
 std::atomic<uint32_t> g_spin_limit{lsd::kSpinLimit};   // empty look-back polls before a tile gives up
 std::atomic<uint32_t> g_mute_row{0};                   // diagnostic builds only (LSD_FAULT_INJECT)
+[[maybe_unused]] std::atomic<int> g_mute_sorts{-1};                     // diagnostic builds only: sorts the muted row still applies to (-1: all)
 std::atomic<int> g_rank_setting{-1};   // -1 auto, 0 mask forms only, 2 returning LDS add wherever probed ok
 
 #ifdef LSD_FAULT_INJECT
@@ -322,8 +330,12 @@ constexpr int kMaxFeedEvents = (int)(((size_t)LSDSORT_MAX_KEYS >> 22) + 3);
 // pass three marks: after its histogram, after its offset scan, after its scatter.
 int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, size_t n, int radix_bits,
              int algorithm, hipStream_t stream, StageEvents* ev, lsdsort_timing* timing,
-             const lsd::KeyTransform& xf = lsd::KeyTransform{}, const HostFeed* feed = nullptr)
+             const lsd::KeyTransform& xf = lsd::KeyTransform{}, const HostFeed* feed = nullptr,
+             uint32_t* const* d_more = nullptr, int more = 0)   // further payload arrays (0..2), chained form only
 {
+    if (more < 0 || more > 2 || (more > 0 && (!d_vals || !d_more || algorithm != LSDSORT_ALGO_ONESWEEP || feed))) return LSDSORT_ERR_INVALID_ARG;
+    for (int e = 0; e < more; e++)
+        if (n > 0 && !d_more[e]) return LSDSORT_ERR_INVALID_ARG;
     if (feed && algorithm != LSDSORT_ALGO_ONESWEEP) return LSDSORT_ERR_INVALID_ARG;
     if (xf.on && (algorithm != LSDSORT_ALGO_ONESWEEP || radix_bits < 4)) return LSDSORT_ERR_UNSUPPORTED;
     if (!valid_radix(radix_bits)) return LSDSORT_ERR_INVALID_ARG;
@@ -337,7 +349,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     const bool pairs = d_vals != nullptr;
     const TileShape* shape = current_shape(radix_bits, pairs, n, algorithm);
     if (!shape) return LSDSORT_ERR_INVALID_ARG;
-    const Layout L = make_layout(n, radix_bits, pairs, algorithm, *shape);
+    const Layout L = make_layout(n, radix_bits, pairs ? 1 + more : 0, algorithm, *shape);
     if (!d_ws || (reinterpret_cast<uintptr_t>(d_ws) & (kAlign - 1)) || ws_bytes < L.total) return LSDSORT_ERR_WORKSPACE;
 
     char* ws = static_cast<char*>(d_ws);
@@ -345,6 +357,14 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     uint32_t* alt_keys = reinterpret_cast<uint32_t*>(ws + L.alt_keys);
     uint32_t* alt_vals = pairs ? reinterpret_cast<uint32_t*>(ws + L.alt_vals) : nullptr;
     const int passes = 32 / radix_bits;
+    uint32_t mute_row = g_mute_row.load(std::memory_order_relaxed);
+#ifdef LSD_FAULT_INJECT
+    {   // "the next k sorts only" (lsdsort_debug_fault_inject_sorts): e.g. the first of the two sorts inside lsdsort_u64_device
+        int left = g_mute_sorts.load(std::memory_order_relaxed);
+        if (left == 0) mute_row = 0;
+        else if (left > 0) g_mute_sorts.store(left - 1, std::memory_order_relaxed);
+    }
+#endif
     if (timing) {
         timing->passes = passes;
         timing->tile_keys = shape->tile();
@@ -429,7 +449,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
         p.num_tiles = L.tiles;
         p.fault = control;
         p.spin_limit = g_spin_limit.load(std::memory_order_relaxed);
-        p.mute_row = g_mute_row.load(std::memory_order_relaxed);
+        p.mute_row = mute_row;
         p.xcd_chunk = g_xcd_chunk.load(std::memory_order_relaxed);
         p.stats = g_stats.load(std::memory_order_relaxed);
         if (algorithm == LSDSORT_ALGO_ONESWEEP) {
@@ -445,6 +465,14 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             p.status_clear = pass + 1 < passes ? reinterpret_cast<uint32_t*>(ws + ((pass & 1) ? L.status : L.status_odd)) : nullptr;
             p.tickets = reinterpret_cast<uint32_t*>(ws + L.tickets) + (size_t)pass * lsd::kMaxRegions;
             p.parity = 0;
+            // further payload arrays ping-pong like the first: even passes read the caller's, odd passes the alternates
+            p.num_payloads = pairs ? (uint32_t)(1 + more) : 0u;
+            for (int e = 0; e < more; e++) {
+                uint32_t* mine = d_more[e];
+                uint32_t* alt = reinterpret_cast<uint32_t*>(ws + L.alt_more[e]);
+                p.more_in[e] = (pass & 1) && !plan ? alt : mine;
+                p.more_out[e] = (pass & 1) && !plan ? mine : alt;
+            }
             if (plan) {   // the same pair for every pass: the plan says which way round (and whether at all)
                 p.in = d_keys;
                 p.out = alt_keys;
@@ -480,7 +508,12 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     }
     // 32 / radix_bits is even for every accepted radix: the result is back in d_keys/d_vals,
     // as the reference relies on (.cu:905, .cu:1005) -- unless the plan skipped an odd number of passes
-    if (plan) LSD_HIP(lsd::launch_finish_plan(plan + 2 * passes, d_keys, alt_keys, d_vals, alt_vals, (uint32_t)n, stream));
+    if (plan) {
+        LSD_HIP(lsd::launch_finish_plan(plan + 2 * passes, d_keys, alt_keys, d_vals, alt_vals, (uint32_t)n, stream));
+        for (int e = 0; e < more; e++)   // the same copy back for each further payload array
+            LSD_HIP(lsd::launch_finish_plan(plan + 2 * passes, d_more[e], reinterpret_cast<uint32_t*>(ws + L.alt_more[e]), nullptr, nullptr,
+                                            (uint32_t)n, stream));
+    }
     return LSDSORT_OK;
 }
 
@@ -676,6 +709,12 @@ LSDSORT_API int lsdsort_debug_fault_inject(unsigned spin_limit, unsigned mute_ro
 #endif
 
 #ifdef LSD_FAULT_INJECT
+LSDSORT_API int lsdsort_debug_fault_inject_sorts(int sorts)   // the muted row applies to the next `sorts` sorts only (-1: to all)
+{
+    g_mute_sorts.store(sorts, std::memory_order_relaxed);
+    return LSDSORT_OK;
+}
+
 LSDSORT_API int lsdsort_debug_corrupt_counts(unsigned from_word, unsigned to_word, unsigned delta, unsigned keep_sum)
 {
     CorruptCounts c;
@@ -750,15 +789,16 @@ size_t lsdsort_workspace_bytes_ex(size_t n, int radix_bits, int pairs, int algor
     // class at that class's largest n (smaller tiles mean more status rows per key) -- so that a
     // workspace made for n serves every smaller sort as well; each term, hence the figure, is
     // monotonic in n.
-    size_t need = make_layout(n, radix_bits, pairs != 0, algorithm, *current_shape(radix_bits, pairs != 0, n, algorithm)).total;
+    if (pairs < 0 || pairs > 3) return 0;
+    size_t need = make_layout(n, radix_bits, pairs, algorithm, *current_shape(radix_bits, pairs != 0, n, algorithm)).total;
     if (algorithm == LSDSORT_ALGO_ONESWEEP) {
         for (int c = 0; c < kNumShapeClasses && kShapeClasses[c].below <= n; c++) {
             const size_t m = kShapeClasses[c].below - 1;
-            const size_t t = make_layout(m, radix_bits, pairs != 0, algorithm, *current_shape(radix_bits, pairs != 0, m, algorithm)).total;
+            const size_t t = make_layout(m, radix_bits, pairs, algorithm, *current_shape(radix_bits, pairs != 0, m, algorithm)).total;
             if (t > need) need = t;
         }
     }
-    const size_t stage = make_layout(n, radix_bits, pairs != 0, algorithm, *current_shape(radix_bits, pairs != 0, 0, algorithm)).total;
+    const size_t stage = make_layout(n, radix_bits, pairs, algorithm, *current_shape(radix_bits, pairs != 0, 0, algorithm)).total;
     return need > stage ? need : stage;
 }
 
@@ -787,6 +827,22 @@ int lsdsort_pairs_u32_device(uint32_t* d_keys, uint32_t* d_vals, void* d_workspa
     if (n > 0 && !d_vals) return LSDSORT_ERR_INVALID_ARG;
     return lsdsort_u32_device_ex(d_keys, d_vals, d_workspace, workspace_bytes, n, radix_bits, LSDSORT_ALGO_ONESWEEP,
                                  hip_stream);
+}
+
+int lsdsort_multi_u32_device(uint32_t* d_keys, uint32_t* const* d_vals, int num_vals, void* d_workspace, size_t workspace_bytes,
+                             size_t n, int radix_bits, void* hip_stream)
+{
+    if (num_vals < 1 || num_vals > 3 || !d_vals) return LSDSORT_ERR_INVALID_ARG;
+    if (n > 0 && !d_vals[0]) return LSDSORT_ERR_INVALID_ARG;
+    // the key/value kernel sends further payload arrays through its single-round shapes only (every default shape is one)
+    const TileShape* shape = current_shape(radix_bits, true, n, LSDSORT_ALGO_ONESWEEP);
+    if (num_vals > 1 && shape && valid_radix(radix_bits)) {
+        const TileShape* shapes = nullptr;
+        (void)lsd::tile_shapes(radix_bits, &shapes);
+        if (!lsd::single_round_shape(radix_bits, (int)(shape - shapes))) return LSDSORT_ERR_UNSUPPORTED;
+    }
+    return run_sort(d_keys, d_vals[0], d_workspace, workspace_bytes, n, radix_bits, LSDSORT_ALGO_ONESWEEP,
+                    static_cast<hipStream_t>(hip_stream), nullptr, nullptr, lsd::KeyTransform{}, nullptr, d_vals + 1, num_vals - 1);
 }
 
 int lsdsort_keys_device(void* d_keys, uint32_t* d_vals, void* d_workspace, size_t workspace_bytes, size_t n,

@@ -94,15 +94,21 @@ constexpr int min_waves_per_simd()
 // Look-back geometry: LB status rows per thread per step; the first step is taken by up to four
 // "slots" of threads at once (thread t: digit t % H, slot t / H), so it covers SLOTS*LB predecessors
 // with one round trip.
-template <int R, int T>
+template <int R, int T, int K = 32>
 struct Lookback {
     static constexpr int H = 1 << R;
     // rows per step, measured on 2^28 keys (tools/ab_bench.sh): 2 -> 0.534, 4 -> 0.551, 8 -> 0.553 ms/pass at
     // 8-bit digits: a step costs a round trip whatever its width, but every row is 1 KiB of status reads
+    // Small sorts (the 16-keys-per-thread shapes, n < 2^21): every tile of a chain starts at the same moment, nobody has a
+    // prefix to offer early, and a tile walks its whole chain of aggregates -- there the width of a step is what counts
+    // (LSD_LB_SMALL, tools/size_sweep.py).
+#ifndef LSD_LB_SMALL
+#define LSD_LB_SMALL 2
+#endif
 #ifdef LSD_LB   // experiment builds (make variant / stats DEFS=-DLSD_LB=n)
-    static constexpr int LB = H >= 64 ? LSD_LB : 8;
+    static constexpr int LB = H >= 64 ? (K <= 16 && T <= 512 ? LSD_LB_SMALL : LSD_LB) : 8;
 #else
-    static constexpr int LB = H >= 64 ? 2 : 8;
+    static constexpr int LB = H >= 64 ? (K <= 16 && T <= 512 ? LSD_LB_SMALL : 2) : 8;
 #endif
     static constexpr int SLOTS = 1;   // measured: helper slots (2 or 4) buy nothing here, the extra barrier costs a little
     static constexpr int LDS_WORDS = (SLOTS - 1) * LB * H;
@@ -116,7 +122,7 @@ constexpr int rank_scatter_lds_words()
     constexpr int keys_words = CAP;
     constexpr int tab_words = RANK == kRankLdsOr ? W * H * 2 : 0;
     constexpr int buf = keys_words > tab_words ? keys_words : tab_words;
-    return buf + W * H + H + 32 + Lookback<R, T>::LDS_WORDS;
+    return buf + W * H + H + 32 + Lookback<R, T, K>::LDS_WORDS;
 }
 
 // XF: this launch may carry a key transform (PassParams::xin on a sort's first pass, ::xout on its last);
@@ -136,8 +142,8 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     constexpr int KEYS_WORDS = CAP;
     constexpr int TAB_WORDS = RANK == kRankLdsOr ? W * H * 2 : 0;
     constexpr int BUF_WORDS = KEYS_WORDS > TAB_WORDS ? KEYS_WORDS : TAB_WORDS;
-    constexpr int LB = Lookback<R, T>::LB;          // status rows per thread per look-back step
-    constexpr int LSLOTS = Lookback<R, T>::SLOTS;   // thread slots sharing the first step
+    constexpr int LB = Lookback<R, T, K>::LB;          // status rows per thread per look-back step
+    constexpr int LSLOTS = Lookback<R, T, K>::SLOTS;   // thread slots sharing the first step
     static_assert(T % kWave == 0 && H <= T, "one thread per digit in the tile scan");
     static_assert(TILE % CAP == 0 && CAP % T == 0 && (CAP & (CAP - 1)) == 0, "rounds must tile the tile");
 
@@ -189,6 +195,9 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         h1 = na >= nb ? a : b;
         const uint64_t rest = ~(na >= nb ? ma : mb);
         h2 = rest != 0ull ? (uint32_t)__builtin_amdgcn_readlane((int)d, (int)__builtin_ctzll(rest)) : kNoDigit;
+        // a second value is worth its ballots only if it is frequent as well (eight lanes of the row); otherwise its
+        // few holders take their atomics like everybody else and the careful loop counts ONE value
+        if (h2 != kNoDigit && popc64_add(__ballot(d == h2), 0u) < 8u) h2 = kNoDigit;
         return true;
     };
     auto row_is_heavy = [&](uint32_t d) -> bool {
@@ -244,38 +253,65 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         // MI355X guide: never assume any of them).  A workgroup serves the region of its own XCD
         // first (hardware XCC_ID) and moves on to the others when that one is used up: placement is
         // for speed only (neighbouring runs meet in one L2; each XCD walks its own short chain).
-        if (tid == 0) {
+        if (wave == 0) {
             uint32_t xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            uint32_t got = 0xFFFFFFFFu;
             // home regions of this XCD first (spread over them by block index), then everyone else's
             constexpr uint32_t NREG = (uint32_t)regions_for_radix(R);
             constexpr uint32_t PER_XCD = NREG >= (uint32_t)kXcds ? NREG / (uint32_t)kXcds : 1u;
             const uint32_t home = NREG >= (uint32_t)kXcds ? (xcc & (uint32_t)(kXcds - 1)) * PER_XCD + (blockIdx.x / (uint32_t)kXcds) % PER_XCD : 0u;
-            // a skipped pass (plan) takes no ticket: "no tile" below sends every workgroup home
-            for (uint32_t a = 0; a < (plan_skip ? 0u : NREG); a++) {
-                const uint32_t x = (home + a) % NREG;
-                // Home region: ticket and extents in ONE round trip (the ticket is taken before the
-                // tile count is known; an over-run ticket of an exhausted region is harmless).
-                // Other regions: look at the (cached) tile count first, so that walking past empty
-                // regions (skewed digits leave most of them empty) costs loads, not atomics.
-                const uint32_t region_tiles = p.regions[2 * kMaxRegions + x];
-                if (a > 0 && region_tiles == 0) continue;
-                const uint32_t r_start = p.regions[x], r_len = p.regions[kMaxRegions + x], row0 = p.regions[3 * kMaxRegions + x];
-                const uint32_t ticket = atomicAdd(p.tickets + x, 1u);
-                // the extents are needed only by a winning ticket, and the optimiser would sink their loads
-                // behind the comparison: a second dependent round trip (0.5 us) per tile
-                asm volatile("" : : "v"(r_start), "v"(r_len), "v"(row0));
-                if (ticket < region_tiles) {
-                    got = x;
-                    s_misc[24] = r_start;
-                    s_misc[25] = r_len;
-                    s_misc[26] = row0;
-                    s_misc[29] = ticket;
-                    break;
+            // The home region first, by lane 0 alone: ticket and extents in ONE round trip (the ticket is taken before the tile
+            // count is known; an over-run ticket of an exhausted region is harmless).  Uniform keys never get past this.
+            uint32_t x = home;
+            uint32_t r_tiles = 0, r_start = 0, r_len = 0, row0 = 0, my_ticket = 0;
+            if (lane == 0 && !plan_skip) {   // a skipped pass (plan) takes no ticket: "no tile" below sends every workgroup home
+                r_tiles = p.regions[2 * kMaxRegions + x];
+                r_start = p.regions[x];
+                r_len = p.regions[kMaxRegions + x];
+                row0 = p.regions[3 * kMaxRegions + x];
+                my_ticket = atomicAdd(p.tickets + x, 1u);
+            }
+            // the extents are needed only by a winning ticket, and the optimiser would sink their loads behind the
+            // comparison: a second dependent round trip (0.5 us) per tile
+            asm volatile("" : : "v"(r_start), "v"(r_len), "v"(row0));
+            uint32_t winner = __ballot(lane == 0 && my_ticket < r_tiles) ? 0u : 64u;   // uniform
+            if (NREG > 1 && winner == 64u && !plan_skip) {
+                // Home is used up.  Lane a looks at region (home + a) % NREG, all of them in one more round trip: how many
+                // tiles, and how far its dispenser has got (a relaxed load: a lower bound, which is all the choice needs).
+                // The workgroup then goes straight to the first region that still has tiles instead of finding out one atomic
+                // round trip per exhausted region: with skewed digits (one region holding 90 % of a pass's keys) that walk
+                // was 7.4 of a tile's 22 us at 4-bit digits, 16 regions (tools/phase_stats.py --radix 4 --heavy 90, round 3).
+                const bool mine = lane != 0 && lane < NREG;
+                uint32_t seen = 0;
+                if (mine) {
+                    x = (home + lane) % NREG;
+                    r_tiles = p.regions[2 * kMaxRegions + x];
+                    r_start = p.regions[x];
+                    r_len = p.regions[kMaxRegions + x];
+                    row0 = p.regions[3 * kMaxRegions + x];
+                    seen = load_status(p.tickets + x);
+                }
+                uint64_t open = __ballot(mine && seen < r_tiles);   // regions that had tickets left when looked at
+                while (winner == 64u && open != 0ull) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(open);
+                    uint32_t t = 0xFFFFFFFFu;
+                    if (lane == l) t = atomicAdd(p.tickets + x, 1u);
+                    if (__ballot(lane == l && t < r_tiles)) {
+                        winner = l;
+                        if (lane == l) my_ticket = t;
+                    } else {
+                        open &= ~(1ull << l);   // used up in the meantime
+                    }
                 }
             }
-            s_misc[28] = got;
+            if (lane == winner) {   // no lane when there is no tile left
+                s_misc[24] = r_start;
+                s_misc[25] = r_len;
+                s_misc[26] = row0;
+                s_misc[29] = my_ticket;
+                s_misc[28] = x;
+            }
+            if (winner == 64u && lane == 0) s_misc[28] = 0xFFFFFFFFu;
         }
         __syncthreads();
         region = __builtin_amdgcn_readfirstlane(s_misc[28]);
@@ -313,14 +349,23 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     uint32_t* out_keys = p.out;
     const uint32_t* in_vals = p.vals_in;
     uint32_t* out_vals = p.vals_out;
-    if (CHAINED && p.plan) {
-        if (plan_swapped) {
-            in_keys = p.out;
-            out_keys = const_cast<uint32_t*>(p.in);
-            in_vals = p.vals_out;
-            out_vals = const_cast<uint32_t*>(p.vals_in);
-        }
+    const bool swapped = CHAINED && p.plan && plan_swapped;
+    if (swapped) {
+        in_keys = p.out;
+        out_keys = const_cast<uint32_t*>(p.in);
+        in_vals = p.vals_out;
+        out_vals = const_cast<uint32_t*>(p.vals_in);
     }
+    // payload array e of this launch (e = 0: in_vals / out_vals above), the way round the plan says
+    auto payload_in = [&](uint32_t e) -> const uint32_t* {
+        if (e == 0) return in_vals;
+        return swapped ? p.more_out[e - 1] : p.more_in[e - 1];
+    };
+    auto payload_out = [&](uint32_t e) -> uint32_t* {
+        if (e == 0) return out_vals;
+        return swapped ? const_cast<uint32_t*>(p.more_in[e - 1]) : p.more_out[e - 1];
+    };
+    const uint32_t num_payloads = PAIRS ? (p.num_payloads > 1u ? p.num_payloads : 1u) : 0u;   // uniform
 #ifdef LSD_PHASE_STATS
     stat_row__ = tile;
     if (tid == 0 && p.stats) {
@@ -428,15 +473,26 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             }
             // ... then the holders are ranked from the running counts: vector and scalar ALU only
             uint32_t c1 = 0, c2 = 0;
+            if (h2 != kNoDigit) {   // uniform
 #pragma unroll
-            for (int i = 0; i < K; i++) {
-                const uint32_t d = digit_of(key[i]);
-                const bool in1 = d == h1, in2 = d == h2;
-                const uint64_t m1 = __ballot(in1), m2 = __ballot(in2);
-                const uint32_t r1 = mbcnt_add(m1, c1), r2 = mbcnt_add(m2, c2);
-                rank[i] = in1 ? r1 : (in2 ? r2 : rank[i]);
-                c1 = popc64_add(m1, c1);
-                c2 = popc64_add(m2, c2);
+                for (int i = 0; i < K; i++) {
+                    const uint32_t d = digit_of(key[i]);
+                    const bool in1 = d == h1, in2 = d == h2;
+                    const uint64_t m1 = __ballot(in1), m2 = __ballot(in2);
+                    const uint32_t r1 = mbcnt_add(m1, c1), r2 = mbcnt_add(m2, c2);
+                    rank[i] = in1 ? r1 : (in2 ? r2 : rank[i]);
+                    c1 = popc64_add(m1, c1);
+                    c2 = popc64_add(m2, c2);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; i++) {
+                    const bool in1 = digit_of(key[i]) == h1;
+                    const uint64_t m1 = __ballot(in1);
+                    const uint32_t r1 = mbcnt_add(m1, c1);
+                    rank[i] = in1 ? r1 : rank[i];
+                    c1 = popc64_add(m1, c1);
+                }
             }
             if (lane == 0) {
                 s_cnt[wave * H + h1] = c1;
@@ -553,8 +609,8 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     // pair instead of 3.  With several rounds keys stay live across rounds, so the payloads are
     // fetched here and land while the keys are reordered.
     uint32_t val[PAIRS ? K : 1];
-    auto load_vals = [&]() {
-        const uint32_t* const vals_in = in_vals + first;
+    auto load_vals = [&](uint32_t e = 0) {
+        const uint32_t* const vals_in = payload_in(e) + first;
         if (full) {
 #pragma unroll
             for (int i = 0; i < K; i++) val[i] = vals_in[i * kWave];
@@ -816,25 +872,31 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
 
         // ---- 6. payloads follow their keys through the same slots -----------------------------
         if (PAIRS) {
-            lds_barrier();   // every key of this round has been read back
+            // one payload array after the other (records carry up to three: wide.hip); with a single round the next array's
+            // loads are issued as soon as this one's registers have gone to LDS, so they land while it is stored
+            for (uint32_t e = 0; e < num_payloads; e++) {
+                lds_barrier();   // every key (or payload e - 1) of this round has been read back
 #pragma unroll
-            for (int i = 0; i < K; i++) {
-                if (ROUNDS == 1) s_keys[pos_at(i)] = val[i];
-                else if ((pos_at(i) / (uint32_t)CAP) == (uint32_t)round) s_keys[pos_at(i) % (uint32_t)CAP] = val[i];
-            }
-            lds_barrier();
-            auto val_slots = [&](auto all_valid) {
-#pragma unroll
-                for (int s2 = 0; s2 < SLOTS; s2++) {
-                    const uint32_t slot = s2 * T + tid;
-                    const uint32_t q = round * CAP + slot;
-                    const uint32_t d = (dbytes[s2 / 4] >> (8 * (s2 & 3))) & 0xFFu;
-                    if (decltype(all_valid)::value || q < valid) out_vals[s_gdelta[d] + q] = s_keys[slot];
-                    if ((s2 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < K; i++) {
+                    if (ROUNDS == 1) s_keys[pos_at(i)] = val[i];
+                    else if ((pos_at(i) / (uint32_t)CAP) == (uint32_t)round) s_keys[pos_at(i) % (uint32_t)CAP] = val[i];
                 }
-            };
-            if (full) val_slots(std::true_type{});
-            else val_slots(std::false_type{});
+                if (ROUNDS == 1 && e + 1 < num_payloads) load_vals(e + 1);
+                lds_barrier();
+                uint32_t* const vals_to = payload_out(e);
+                auto val_slots = [&](auto all_valid) {
+#pragma unroll
+                    for (int s2 = 0; s2 < SLOTS; s2++) {
+                        const uint32_t slot = s2 * T + tid;
+                        const uint32_t q = round * CAP + slot;
+                        const uint32_t d = (dbytes[s2 / 4] >> (8 * (s2 & 3))) & 0xFFu;
+                        if (decltype(all_valid)::value || q < valid) vals_to[s_gdelta[d] + q] = s_keys[slot];
+                        if ((s2 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                if (full) val_slots(std::true_type{});
+                else val_slots(std::false_type{});
+            }
         }
     }
     // Housekeeping for the next pass goes LAST: nothing is waited for behind it.  (Placed in front of the read-back, as

@@ -7,9 +7,11 @@
 //   uint64 keys only            : split (lo[], hi[]) | pairs sort by lo carrying hi | pairs sort by hi carrying lo | merge.
 //                                 8 passes at 8-bit digits, 16 B/key/pass -- what a native 64-bit-key pass would move --
 //                                 plus the split and the merge (16 B/key each) and the two upfront histogram reads.
-//   uint64 keys + 32/64-bit payloads, uint32 keys + 64-bit payloads: sort an index instead of the records --
-//                                 idx = 0..n-1 rides through the pairs sorts (for 64-bit keys: by lo, then by the high
-//                                 words gathered into that order) and the records are gathered once at the end.
+//   uint64 keys + 32/64-bit payloads, uint32 keys + 64-bit payloads (records): every word that is not the key word being
+//                                 sorted on rides through the passes as a payload array of its own (the key/value kernel
+//                                 carries up to three: lsdsort_multi_u32_device) -- 64/64: by lo carrying (hi, vlo, vhi), then by
+//                                 hi carrying (lo, vlo, vhi).  No gather: round 2 sorted an index and gathered the records at
+//                                 random at the end, which cost more than the passes (13.5 ms of a 64/64 sort of 2^27 records).
 // Everything is stream-ordered on the caller's stream and allocates nothing (workspace), like the 32-bit entries.
 #define LSDSORT_BUILD 1
 #include "../../include/lsdsort.h"
@@ -66,31 +68,20 @@ __global__ void __launch_bounds__(kThreads) merge_u64_kernel(const uint32_t* __r
         out[i] = make_uint2(lo[i], hi[i]);
 }
 
-__global__ void __launch_bounds__(kThreads) iota_kernel(uint32_t* __restrict__ out, size_t n)
+// sticky[0] |= fault[0] (one thread; stream-ordered behind the sort whose fault word it keeps)
+__global__ void keep_fault_kernel(uint32_t* sticky, const uint32_t* fault)
 {
-    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) out[i] = (uint32_t)i;
-}
-
-// out[i] = high word of src[idx[i]]
-__global__ void __launch_bounds__(kThreads) gather_hi_kernel(const uint2* __restrict__ src, const uint32_t* __restrict__ idx,
-                                                            uint32_t* __restrict__ out, size_t n)
-{
-    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) out[i] = src[idx[i]].y;
-}
-
-template <typename V>
-__global__ void __launch_bounds__(kThreads) gather_kernel(const V* __restrict__ src, const uint32_t* __restrict__ idx,
-                                                         V* __restrict__ out, size_t n)
-{
-    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) out[i] = src[idx[i]];
+    if (*fault) *sticky |= *fault;
 }
 
 struct WideLayout {
-    size_t a = 0, b = 0, c = 0;     // three uint32[n] arrays (lo / hi / idx / gathered high words, by entry)
-    size_t rec_keys = 0;            // uint64[n]: gathered keys      (record forms)
-    size_t rec_vals = 0;            // uint64[n]: gathered payloads  (record forms)
-    size_t sort_ws = 0;             // workspace of the pairs sort
+    size_t sticky = 0;              // u32: fault words of every sort inside the call, ORed together (each sort's opening
+                                    // memset clears the shared sort workspace's own word, so the first sort's would be lost)
+    size_t a = 0, b = 0;            // uint32[n]: low / high key words (64-bit keys)
+    size_t c = 0, d = 0;            // uint32[n]: low / high payload words (64-bit payloads)
+    size_t sort_ws = 0;             // workspace of the sorts inside
     size_t sort_ws_bytes = 0;
+    int payloads = 1;               // payload arrays the sorts inside carry
     size_t total = 0;
 };
 
@@ -99,16 +90,20 @@ WideLayout make_wide_layout(size_t n, int radix_bits, int key_bits, int val_bits
 {
     WideLayout L;
     size_t off = 0;
+    L.sticky = off; off += kAlign;
     const size_t words = align_up(n * sizeof(uint32_t));
-    L.a = off; off += words;
-    L.b = off; off += words;
-    if (val_bits != 0 && key_bits == 64) { L.c = off; off += words; }
-    if (val_bits != 0) {
-        L.rec_keys = off; off += align_up(n * sizeof(uint64_t));
-        L.rec_vals = off; off += align_up(n * sizeof(uint64_t));
+    if (key_bits == 64) {
+        L.a = off; off += words;
+        L.b = off; off += words;
     }
+    if (val_bits == 64) {
+        L.c = off; off += words;
+        L.d = off; off += words;
+    }
+    // what rides with the key word: the other key word (64-bit keys) and the payload's words
+    L.payloads = (key_bits == 64 ? 1 : 0) + val_bits / 32;
     L.sort_ws = off;
-    L.sort_ws_bytes = lsdsort_workspace_bytes(n, radix_bits, 1);
+    L.sort_ws_bytes = lsdsort_workspace_bytes(n, radix_bits, L.payloads);
     off += align_up(L.sort_ws_bytes);
     L.total = off;
     return L;
@@ -149,11 +144,16 @@ int lsdsort_u64_device(uint64_t* d_keys, void* d_workspace, size_t workspace_byt
     char* ws = static_cast<char*>(d_workspace);
     uint32_t* lo = reinterpret_cast<uint32_t*>(ws + L.a);
     uint32_t* hi = reinterpret_cast<uint32_t*>(ws + L.b);
+    uint32_t* sticky = reinterpret_cast<uint32_t*>(ws + L.sticky);
+    const uint32_t* fault = reinterpret_cast<const uint32_t*>(ws + L.sort_ws);   // the sorts' fault word: first word of their workspace
+    W_HIP(hipMemsetAsync(sticky, 0, sizeof(uint32_t), s));
     hipLaunchKernelGGL(split_u64_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, reinterpret_cast<const uint2*>(d_keys), lo, hi, n);
     W_HIP(hipGetLastError());
     // low word first, then a stable sort on the high word: sorted by (hi, lo) -- the LSD argument, one word at a time
     W_TRY(lsdsort_pairs_u32_device(lo, hi, ws + L.sort_ws, L.sort_ws_bytes, n, radix_bits, s));
+    hipLaunchKernelGGL(keep_fault_kernel, dim3(1), dim3(1), 0, s, sticky, fault);   // the next sort's memset clears that word
     W_TRY(lsdsort_pairs_u32_device(hi, lo, ws + L.sort_ws, L.sort_ws_bytes, n, radix_bits, s));
+    hipLaunchKernelGGL(keep_fault_kernel, dim3(1), dim3(1), 0, s, sticky, fault);
     hipLaunchKernelGGL(merge_u64_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, lo, hi, reinterpret_cast<uint2*>(d_keys), n);
     W_HIP(hipGetLastError());
     return LSDSORT_OK;
@@ -171,40 +171,47 @@ int lsdsort_records_device(void* d_keys, void* d_vals, int key_bits, int val_bit
     W_TRY(lsdsort_prepare_device());
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     char* ws = static_cast<char*>(d_workspace);
-    uint32_t* word = reinterpret_cast<uint32_t*>(ws + L.a);     // the key word being sorted on
-    uint32_t* idx = reinterpret_cast<uint32_t*>(ws + L.b);
     const uint32_t g = grid_for(n);
-    hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(kThreads), 0, s, idx, n);
+    uint32_t* sticky = reinterpret_cast<uint32_t*>(ws + L.sticky);
+    const uint32_t* fault = reinterpret_cast<const uint32_t*>(ws + L.sort_ws);
+    W_HIP(hipMemsetAsync(sticky, 0, sizeof(uint32_t), s));
+    // the words of the records as arrays of their own: 32-bit members are used where they lie
+    uint32_t* klo = key_bits == 64 ? reinterpret_cast<uint32_t*>(ws + L.a) : static_cast<uint32_t*>(d_keys);
+    uint32_t* khi = key_bits == 64 ? reinterpret_cast<uint32_t*>(ws + L.b) : nullptr;
+    uint32_t* vlo = val_bits == 64 ? reinterpret_cast<uint32_t*>(ws + L.c) : static_cast<uint32_t*>(d_vals);
+    uint32_t* vhi = val_bits == 64 ? reinterpret_cast<uint32_t*>(ws + L.d) : nullptr;
     if (key_bits == 64) {
-        uint32_t* high = reinterpret_cast<uint32_t*>(ws + L.c);
-        hipLaunchKernelGGL(split_u64_kernel, dim3(g), dim3(kThreads), 0, s, reinterpret_cast<const uint2*>(d_keys), word, (uint32_t*)nullptr, n);
+        hipLaunchKernelGGL(split_u64_kernel, dim3(g), dim3(kThreads), 0, s, static_cast<const uint2*>(d_keys), klo, khi, n);
         W_HIP(hipGetLastError());
-        W_TRY(lsdsort_pairs_u32_device(word, idx, ws + L.sort_ws, L.sort_ws_bytes, n, radix_bits, s));            // order by the low word
-        hipLaunchKernelGGL(gather_hi_kernel, dim3(g), dim3(kThreads), 0, s, reinterpret_cast<const uint2*>(d_keys), idx, high, n);
-        W_HIP(hipGetLastError());
-        W_TRY(lsdsort_pairs_u32_device(high, idx, ws + L.sort_ws, L.sort_ws_bytes, n, radix_bits, s));            // stable, by the high word
-    } else {
-        W_HIP(hipMemcpyAsync(word, d_keys, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-        W_TRY(lsdsort_pairs_u32_device(word, idx, ws + L.sort_ws, L.sort_ws_bytes, n, radix_bits, s));
-    }
-    // idx[i] = where the i-th smallest record sits: gather the records once, copy them back
-    void* rk = ws + L.rec_keys;
-    void* rv = ws + L.rec_vals;
-    if (key_bits == 64) {
-        hipLaunchKernelGGL((gather_kernel<uint2>), dim3(g), dim3(kThreads), 0, s, static_cast<const uint2*>(d_keys), idx, static_cast<uint2*>(rk), n);
-        W_HIP(hipGetLastError());
-        W_HIP(hipMemcpyAsync(d_keys, rk, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
-    } else {
-        W_HIP(hipMemcpyAsync(d_keys, word, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));   // the sorted key words themselves
     }
     if (val_bits == 64) {
-        hipLaunchKernelGGL((gather_kernel<uint2>), dim3(g), dim3(kThreads), 0, s, static_cast<const uint2*>(d_vals), idx, static_cast<uint2*>(rv), n);
+        hipLaunchKernelGGL(split_u64_kernel, dim3(g), dim3(kThreads), 0, s, static_cast<const uint2*>(d_vals), vlo, vhi, n);
         W_HIP(hipGetLastError());
-        W_HIP(hipMemcpyAsync(d_vals, rv, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
-    } else {
-        hipLaunchKernelGGL((gather_kernel<uint32_t>), dim3(g), dim3(kThreads), 0, s, static_cast<const uint32_t*>(d_vals), idx, static_cast<uint32_t*>(rv), n);
+    }
+    // LSD over the key's words, low word first; everything else rides as payload arrays (stable: ties keep their order)
+    {
+        uint32_t* pay[3];
+        int np = 0;
+        if (khi) pay[np++] = khi;
+        pay[np++] = vlo;
+        if (vhi) pay[np++] = vhi;
+        W_TRY(lsdsort_multi_u32_device(klo, pay, np, ws + L.sort_ws, L.sort_ws_bytes, n, radix_bits, s));
+        hipLaunchKernelGGL(keep_fault_kernel, dim3(1), dim3(1), 0, s, sticky, fault);
+    }
+    if (khi) {
+        uint32_t* pay[3];
+        int np = 0;
+        pay[np++] = klo;
+        pay[np++] = vlo;
+        if (vhi) pay[np++] = vhi;
+        W_TRY(lsdsort_multi_u32_device(khi, pay, np, ws + L.sort_ws, L.sort_ws_bytes, n, radix_bits, s));
+        hipLaunchKernelGGL(keep_fault_kernel, dim3(1), dim3(1), 0, s, sticky, fault);
+        hipLaunchKernelGGL(merge_u64_kernel, dim3(g), dim3(kThreads), 0, s, klo, khi, static_cast<uint2*>(d_keys), n);
         W_HIP(hipGetLastError());
-        W_HIP(hipMemcpyAsync(d_vals, rv, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    }
+    if (vhi) {
+        hipLaunchKernelGGL(merge_u64_kernel, dim3(g), dim3(kThreads), 0, s, vlo, vhi, static_cast<uint2*>(d_vals), n);
+        W_HIP(hipGetLastError());
     }
     return LSDSORT_OK;
 }
@@ -214,7 +221,9 @@ int lsdsort_wide_check_device(void* d_workspace, size_t n, int radix_bits, int k
     if (!d_workspace) return LSDSORT_ERR_WORKSPACE;
     if (!wide_combo(key_bits, val_bits) || lsdsort_workspace_bytes(1, radix_bits, 1) == 0) return LSDSORT_ERR_INVALID_ARG;
     const WideLayout L = make_wide_layout(n, radix_bits, key_bits, val_bits);
-    return lsdsort_check_device(static_cast<char*>(d_workspace) + L.sort_ws, hip_stream);
+    if (n == 0) return LSDSORT_OK;   // an empty call touches nothing
+    // the sticky word holds every inner sort's fault word (lsdsort_check_device reads the first word of what it is given)
+    return lsdsort_check_device(static_cast<char*>(d_workspace) + L.sticky, hip_stream);
 }
 
 }  // extern "C"

@@ -32,6 +32,34 @@ raw.lsdsort_debug_corrupt_counts.restype = ctypes.c_int
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "keys"
 pairs = mode in ("pairs", "counts_pairs")
+
+if mode == "wide":
+    # lsdsort_u64_device runs TWO key/value sorts in one shared workspace, and the second sort's opening memset
+    # clears the fault word the first one raised.  The muted row applies to the FIRST inner sort only
+    # (lsdsort_debug_fault_inject_sorts(1)); lsdsort_wide_check_device must still report it (sticky word in the wide layout).
+    raw.lsdsort_debug_fault_inject_sorts.argtypes = [ctypes.c_int]
+    n64 = (1 << 22) + 77
+    rng = np.random.default_rng(9)
+    host64 = rng.integers(0, 1 << 63, size=n64, dtype=np.uint64)
+    d = torch.from_numpy(host64.view(np.int64)).cuda()
+    wb = int(L.lsdsort_wide_workspace_bytes(n64, 8, 64, 0))
+    ws64 = torch.empty(wb, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    raw.lsdsort_debug_fault_inject(4000, 5 + 1)
+    raw.lsdsort_debug_fault_inject_sorts(1)
+    out = {"mode": mode}
+    t0 = time.time()
+    out["launch_status"] = L.lsdsort_u64_device(d.data_ptr(), ws64.data_ptr(), wb, n64, 8, stream)
+    out["check_status"] = L.lsdsort_wide_check_device(ws64.data_ptr(), n64, 8, 64, 0, stream)
+    out["drain_seconds"] = round(time.time() - t0, 3)
+    raw.lsdsort_debug_fault_inject(0, 0)
+    raw.lsdsort_debug_fault_inject_sorts(-1)
+    d.copy_(torch.from_numpy(host64.view(np.int64)).cuda())
+    out["second_status"] = L.lsdsort_u64_device(d.data_ptr(), ws64.data_ptr(), wb, n64, 8, stream)
+    out["second_check"] = L.lsdsort_wide_check_device(ws64.data_ptr(), n64, 8, 64, 0, stream)
+    out["second_sorted"] = bool(np.array_equal(d.cpu().numpy().view(np.uint64), np.sort(host64)))
+    print(json.dumps(out), flush=True)
+    sys.exit(0)
 r = 8
 n = (1 << 23) + 123
 GUARD = 1 << 16                     # int32 words on either side of the keys / bytes on either side of the workspace

@@ -69,3 +69,20 @@ def test_inconsistent_counts_never_store_out_of_bounds(mode):
     if mode == "counts_pairs":
         assert out["second_payload_stable"]
     assert out["guards_intact_after_clean_sort"]
+
+
+@pytest.mark.gpu
+def test_wide_sort_keeps_the_first_inner_sorts_fault():
+    """lsdsort_u64_device = two key/value sorts sharing one workspace; the second one's opening memset clears the fault word
+    (ADVICE r2).  A bounded-wait give-up in the FIRST inner sort only must still come out of lsdsort_wide_check_device
+    (sticky word), and the next call on the same workspace must be clean."""
+    assert os.path.exists(FAULT_LIB)
+    env = dict(os.environ, LSDSORT_LIB=FAULT_LIB)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_fault_worker.py"), "wide"], env=env, capture_output=True,
+                       text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["launch_status"] == 0
+    assert out["check_status"] == -7, out
+    assert out["drain_seconds"] < 30.0, out
+    assert out["second_status"] == 0 and out["second_check"] == 0 and out["second_sorted"], out
