@@ -215,7 +215,7 @@ LSDSORT_API int lsdsort_digit_histograms_u32_device(const uint32_t* d_keys, size
                                                     uint32_t* d_hist, void* hip_stream);
 
 /* ---- multi-GPU building block (one process per GPU) ----------------------------------- */
-/* Stable partition of this rank's shard by the top msb_bits bits (0..3): d_out holds bucket
+/* Stable partition of this rank's shard by the top msb_bits bits (0..4): d_out holds bucket
  * 0, bucket 1, ... contiguously, d_counts[b] (uint64, 2^msb_bits entries) their sizes.  The
  * caller exchanges buckets with its RCCL communicator (all-to-all over xGMI) and then runs
  * lsdsort_u32_device on what it received.  New work; the reference is single-GPU. */
@@ -267,6 +267,11 @@ LSDSORT_API int lsdsort_comm_create(const void* id, int world, int rank, lsdsort
  * are then only good for lsdsort_comm_destroy. */
 LSDSORT_API int lsdsort_comm_create_loopback(int world, lsdsort_comm** out);
 LSDSORT_API int lsdsort_comm_destroy(lsdsort_comm* comm);
+/* Sub-buckets (1, 2 or 4; world x sub_buckets <= 16, and <= 8 under the splitter rule): the step cuts every rank's key range
+ * into that many consecutive sub-ranges, exchanges them one grouped exchange after the other and sorts sub-bucket j on an
+ * internal stream while sub-bucket j + 1 is still on the links -- the exchange hides under the local sort instead of in front
+ * of it.  Collective setting: every rank of the world must use the same value.  Default 1. */
+LSDSORT_API int lsdsort_comm_set_sub_buckets(lsdsort_comm* comm, int sub_buckets);
 LSDSORT_API int lsdsort_comm_world(const lsdsort_comm* comm);
 LSDSORT_API int lsdsort_comm_rank(const lsdsort_comm* comm);
 /* Device workspace for a rank that contributes up to n_local_max keys and may receive up to out_capacity. */
@@ -309,6 +314,9 @@ LSDSORT_API int lsdsort_sharded_u32_device_ex(lsdsort_comm* comm, const uint32_t
  * bucket b or higher: bucket(key) = number of thresholds <= key; 2^32 = no key of this rank does. */
 LSDSORT_API int lsdsort_sharded_thresholds(const uint32_t* gathered, int world, int samples_per_rank, int rank,
                                            uint64_t* thresholds);
+/* The same cut into `parts` (1..8) parts instead of `world`: parts = world x sub-buckets; thresholds[parts - 1]. */
+LSDSORT_API int lsdsort_sharded_thresholds_parts(const uint32_t* gathered, int world, int samples_per_rank, int rank,
+                                                 int parts, uint64_t* thresholds);
 /* After the stream has drained: the fault words of the step's two chained kernels sequences (partition pass, local
  * sort) in a workspace last used with these sizes; LSDSORT_OK or LSDSORT_ERR_DEVICE_FAULT.  Synchronises hip_stream. */
 LSDSORT_API int lsdsort_sharded_check_device(void* d_workspace, size_t n_local, size_t out_capacity, int world,
@@ -321,6 +329,11 @@ LSDSORT_API const char* lsdsort_last_comm_error(void);
  * Returns LSDSORT_ERR_INVALID_ARG for a bad world / rank. */
 LSDSORT_API int lsdsort_sharded_plan(const uint64_t* counts_matrix, int world, int rank, uint64_t* send_offsets,
                                      uint64_t* recv_offsets, uint64_t* n_out, uint64_t* global_offset);
+/* The same with `sub` sub-buckets per rank: bucket_counts is [src][world * sub] (bucket b belongs to rank b / sub, its
+ * sub-bucket b % sub); send_offsets[world * sub] by bucket, recv_offsets[sub * world] by (sub-bucket, source) -- a rank's
+ * output holds sub-bucket 0 from source 0, 1, .. then sub-bucket 1 .. --, sub_sizes[sub]. */
+LSDSORT_API int lsdsort_sharded_plan_sub(const uint64_t* bucket_counts, int world, int sub, int rank, uint64_t* send_offsets,
+                                         uint64_t* recv_offsets, uint64_t* sub_sizes, uint64_t* n_out, uint64_t* global_offset);
 
 /* ---- misc ----------------------------------------------------------------------------- */
 LSDSORT_API const char* lsdsort_strerror(int status);

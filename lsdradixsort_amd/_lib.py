@@ -94,6 +94,7 @@ SIGNATURES = {
     "lsdsort_comm_create": (c_int, [ctypes.c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "lsdsort_comm_create_loopback": (c_int, [c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "lsdsort_comm_destroy": (c_int, [ctypes.c_void_p]),
+    "lsdsort_comm_set_sub_buckets": (c_int, [ctypes.c_void_p, c_int]),
     "lsdsort_comm_world": (c_int, [ctypes.c_void_p]),
     "lsdsort_comm_rank": (c_int, [ctypes.c_void_p]),
     "lsdsort_sharded_workspace_bytes": (c_size, [c_size, c_size, c_int, c_int]),
@@ -104,6 +105,10 @@ SIGNATURES = {
                                               ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p,
                                               c_size, c_int, c_int, ctypes.c_void_p]),
     "lsdsort_sharded_thresholds": (c_int, [ctypes.POINTER(ctypes.c_uint32), c_int, c_int, c_int, ctypes.POINTER(ctypes.c_uint64)]),
+    "lsdsort_sharded_thresholds_parts": (c_int, [ctypes.POINTER(ctypes.c_uint32), c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_uint64)]),
+    "lsdsort_sharded_plan_sub": (c_int, [ctypes.POINTER(ctypes.c_uint64), c_int, c_int, c_int, ctypes.POINTER(ctypes.c_uint64),
+                                         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                                         ctypes.POINTER(ctypes.c_uint64)]),
     "lsdsort_sharded_check_device": (c_int, [ctypes.c_void_p, c_size, c_size, c_int, c_int, ctypes.c_void_p]),
     "lsdsort_sharded_plan": (c_int, [ctypes.POINTER(ctypes.c_uint64), c_int, c_int, ctypes.POINTER(ctypes.c_uint64),
                                      ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),

@@ -786,6 +786,10 @@ __global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __res
                 t[kMaxRegions + lane] = len;
                 t[2 * kMaxRegions + lane] = tiles;
                 t[3 * kMaxRegions + lane] = upto - tiles;
+            } else if (lane < (uint32_t)kMaxRegions) {
+                // a kernel compiled for more regions than this table has (the 4-bit kernels partitioning by one region for
+                // the multi-GPU step) must find the others empty
+                t[2 * kMaxRegions + lane] = 0;
             }
         };
         const uint32_t x = lane < (uint32_t)REG ? lane : 0u;
@@ -1052,6 +1056,17 @@ __global__ void widen_counts_kernel(const uint32_t* __restrict__ in, uint64_t* _
 hipError_t launch_widen_counts(const uint32_t* hist32, uint64_t* counts64, int bins, hipStream_t stream)
 {
     hipLaunchKernelGGL(widen_counts_kernel, dim3(1), dim3(256), 0, stream, hist32, counts64, bins);
+    return hipGetLastError();
+}
+
+__global__ void keep_fault_kernel(uint32_t* sticky, const uint32_t* fault)
+{
+    if (*fault) *sticky |= *fault;
+}
+
+hipError_t launch_keep_fault(uint32_t* sticky, const uint32_t* fault, hipStream_t stream)
+{
+    hipLaunchKernelGGL(keep_fault_kernel, dim3(1), dim3(1), 0, stream, sticky, fault);
     return hipGetLastError();
 }
 

@@ -190,6 +190,10 @@ hipError_t launch_tile_offsets(int radix_bits, const uint32_t* hist, uint32_t* l
 // counts64[b] = hist32[b], b < bins (multi-GPU bucket sizes as uint64).
 hipError_t launch_widen_counts(const uint32_t* hist32, uint64_t* counts64, int bins, hipStream_t stream);
 
+// *sticky |= *fault (stream-ordered): callers that run several sorts in ONE workspace keep each sort's fault word this way --
+// the next sort's opening memset clears the workspace's own word (wide.hip, sharded.hip).
+hipError_t launch_keep_fault(uint32_t* sticky, const uint32_t* fault, hipStream_t stream);
+
 // *out = value (stream-ordered).
 hipError_t launch_store_u64(uint64_t* out, uint64_t value, hipStream_t stream);
 

@@ -603,9 +603,17 @@ MsbLayout make_msb_layout(size_t n, int msb_bits)
 {
     MsbLayout L;
     const int r = msb_bits ? msb_bits : 1;
-    // sized for the smallest tile a partition of up to n keys may use (most rows)
-    const TileShape* shape = current_shape(r);
-    const size_t tile = (size_t)shape->tile();
+    // sized for the smallest tile a partition of up to n keys may use (most rows): the default shape of the stage entries
+    // and every size class's
+    size_t tile = (size_t)current_shape(r)->tile();
+    {
+        const TileShape* shapes = nullptr;
+        const int count = lsd::tile_shapes(r, &shapes);
+        for (int c = 0; c < kNumShapeClasses; c++) {
+            const int id = class_shape(kShapeClasses[c], r);
+            if (id < count && (size_t)shapes[id].tile() < tile) tile = (size_t)shapes[id].tile();
+        }
+    }
     L.rows = (uint32_t)((n + tile - 1) / tile) + 1u;
     L.zero_bytes = align_up(L.status + (size_t)L.rows * ((size_t)1 << r) * sizeof(uint32_t));
     L.table = L.zero_bytes;
@@ -1005,7 +1013,7 @@ int lsdsort_digit_histograms_u32_device(const uint32_t* d_keys, size_t n, int ra
 // ---- multi-GPU building block ----------------------------------------------------------------
 size_t lsdsort_msb_partition_workspace_bytes(size_t n, int msb_bits)
 {
-    if (msb_bits < 0 || msb_bits > 3 || n > LSDSORT_MAX_KEYS) return 0;
+    if (msb_bits < 0 || msb_bits > 4 || n > LSDSORT_MAX_KEYS) return 0;
     return make_msb_layout(n, msb_bits).total;
 }
 
@@ -1016,7 +1024,8 @@ static int partition_impl(const uint32_t* d_in, uint32_t* d_out, size_t n, int m
                           uint64_t* d_counts, void* d_workspace, size_t workspace_bytes, void* hip_stream,
                           hipEvent_t counts_ready = nullptr, int live = -1)
 {
-    if (msb_bits < 0 || msb_bits > 3 || !d_counts) return LSDSORT_ERR_INVALID_ARG;
+    // by bit field: up to sixteen buckets (the 4-bit kernels); by value: eight (the splitters travel in the launch)
+    if (msb_bits < 0 || msb_bits > (splitters ? 3 : 4) || !d_counts) return LSDSORT_ERR_INVALID_ARG;
     if (live < 0) live = (1 << msb_bits) - 1;
     if (live > (1 << msb_bits) - 1) return LSDSORT_ERR_INVALID_ARG;
     if (splitters)

@@ -132,29 +132,38 @@ int log2_world(int world)
     }
 }
 
+constexpr int kMaxBuckets = 16;   // world x sub-buckets: the partition pass takes digits of up to four bits
+
 struct ShardedLayout {
-    size_t vec = 0;        // u64[W + 1]: this rank's bucket counts, then its output capacity
-    size_t all = 0;        // u64[W][W + 1]: everybody's
+    size_t sticky = 0;     // u32: fault words of the step's local sorts, ORed together (they share one workspace, and every
+                           // sort's opening memset clears that workspace's own word)
+    size_t vec = 0;        // u64[B + 1]: this rank's bucket counts, then its output capacity   (B <= kMaxBuckets)
+    size_t all = 0;        // u64[W][B + 1]: everybody's
     size_t part_ws = 0;    // workspace of the partition pass
     size_t send = 0;       // the partitioned shard: bucket 0 | bucket 1 | ...
-    size_t sort_ws = 0;    // workspace of the local sort
+    size_t sort_ws = 0;    // workspace of the local sorts
     size_t samp = 0;       // u32[1 + S]: this rank's sample (count, then keys) for the splitter rule
     size_t samp_all = 0;   // u32[W][1 + S]: everybody's
     size_t total = 0;
     size_t part_ws_bytes = 0, sort_ws_bytes = 0;
 };
 
+// The layout does not depend on the number of sub-buckets a step uses: every table is sized for kMaxBuckets.
 ShardedLayout make_sharded_layout(size_t n_local_max, size_t out_capacity, int world, int radix_bits)
 {
     ShardedLayout L;
-    const int bits = log2_world(world);
     size_t off = 0;
+    L.sticky = off;
+    off += kAlign;
     L.vec = off;
-    off = align_up(off + (size_t)(world + 1) * sizeof(uint64_t));
+    off = align_up(off + (size_t)(kMaxBuckets + 1) * sizeof(uint64_t));
     L.all = off;
-    off = align_up(off + (size_t)world * (world + 1) * sizeof(uint64_t));
+    off = align_up(off + (size_t)world * (kMaxBuckets + 1) * sizeof(uint64_t));
     L.part_ws = off;
-    L.part_ws_bytes = lsdsort_msb_partition_workspace_bytes(n_local_max, bits);
+    for (int bits = 0; bits <= 4; bits++) {   // whichever digit width the step's bucket count asks for
+        const size_t need = lsdsort_msb_partition_workspace_bytes(n_local_max, bits);
+        if (need > L.part_ws_bytes) L.part_ws_bytes = need;
+    }
     off = align_up(off + L.part_ws_bytes);
     L.send = off;
     off = align_up(off + n_local_max * sizeof(uint32_t));
@@ -375,10 +384,14 @@ struct LoopbackTransport final : Transport {
 struct lsdsort_comm {
     Transport* transport = nullptr;
     int world = 1, rank = 0, device = 0;
-    hipStream_t side = nullptr;
+    int sub_buckets = 1;             // lsdsort_comm_set_sub_buckets
+    hipStream_t side = nullptr;      // count / sample exchange beside the partition pass
+    hipStream_t sorter = nullptr;    // local sorts of sub-buckets that have arrived, beside the exchange of the next ones
     hipEvent_t counts_ready = nullptr;
     hipEvent_t sample_ready = nullptr;
-    uint64_t* h_all = nullptr;       // pinned: [W][W + 1]
+    hipEvent_t arrived[4] = {};      // sub-bucket j is complete in the output buffer
+    hipEvent_t sorted_all = nullptr; // the last local sort has finished
+    uint64_t* h_all = nullptr;       // pinned: [W][kMaxBuckets + 1]
     uint32_t* h_samples = nullptr;   // pinned: [W][1 + S]
 };
 
@@ -388,9 +401,12 @@ int finish_comm(lsdsort_comm* c)
 {
     SH_HIP(hipGetDevice(&c->device));
     SH_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    SH_HIP(hipStreamCreateWithFlags(&c->sorter, hipStreamNonBlocking));
     SH_HIP(hipEventCreateWithFlags(&c->counts_ready, hipEventDisableTiming));
     SH_HIP(hipEventCreateWithFlags(&c->sample_ready, hipEventDisableTiming));
-    SH_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_all), (size_t)c->world * (c->world + 1) * sizeof(uint64_t), hipHostMallocDefault));
+    SH_HIP(hipEventCreateWithFlags(&c->sorted_all, hipEventDisableTiming));
+    for (hipEvent_t& e : c->arrived) SH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    SH_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_all), (size_t)c->world * (kMaxBuckets + 1) * sizeof(uint64_t), hipHostMallocDefault));
     SH_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_samples), (size_t)c->world * (1 + LSDSORT_SPLITTER_SAMPLES) * sizeof(uint32_t),
                          hipHostMallocDefault));
     return LSDSORT_OK;
@@ -486,11 +502,22 @@ int lsdsort_comm_destroy(lsdsort_comm* c)
     if (c->h_samples) (void)hipHostFree(c->h_samples);
     if (c->counts_ready) (void)hipEventDestroy(c->counts_ready);
     if (c->sample_ready) (void)hipEventDestroy(c->sample_ready);
+    if (c->sorted_all) (void)hipEventDestroy(c->sorted_all);
+    for (hipEvent_t e : c->arrived)
+        if (e) (void)hipEventDestroy(e);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->sorter) (void)hipStreamDestroy(c->sorter);
     delete c->transport;
     if (switched) (void)hipSetDevice(prev);
     (void)hipGetLastError();
     delete c;
+    return LSDSORT_OK;
+}
+
+int lsdsort_comm_set_sub_buckets(lsdsort_comm* c, int sub_buckets)
+{
+    if (!c || (sub_buckets != 1 && sub_buckets != 2 && sub_buckets != 4) || c->world * sub_buckets > kMaxBuckets) return LSDSORT_ERR_INVALID_ARG;
+    c->sub_buckets = sub_buckets;
     return LSDSORT_OK;
 }
 
@@ -522,9 +549,44 @@ int lsdsort_sharded_plan(const uint64_t* m, int world, int rank, uint64_t* send_
     return LSDSORT_OK;
 }
 
+int lsdsort_sharded_plan_sub(const uint64_t* m, int world, int sub, int rank, uint64_t* send_offsets, uint64_t* recv_offsets,
+                             uint64_t* sub_sizes, uint64_t* n_out, uint64_t* global_offset)
+{
+    if (!m || log2_world(world) < 0 || (sub != 1 && sub != 2 && sub != 4) || world * sub > kMaxBuckets || rank < 0 || rank >= world)
+        return LSDSORT_ERR_INVALID_ARG;
+    const int B = world * sub;
+    uint64_t s = 0;
+    for (int b = 0; b < B; b++) {          // bucket b of my partitioned shard: destination b / sub, its sub-bucket b % sub
+        if (send_offsets) send_offsets[b] = s;
+        s += m[(size_t)rank * B + b];
+    }
+    uint64_t r = 0;
+    for (int j = 0; j < sub; j++) {        // my output: sub-bucket 0 from source 0, 1, .. | sub-bucket 1 from source 0, 1, .. | ...
+        uint64_t size = 0;
+        for (int src = 0; src < world; src++) {
+            if (recv_offsets) recv_offsets[j * world + src] = r;
+            r += m[(size_t)src * B + rank * sub + j];
+            size += m[(size_t)src * B + rank * sub + j];
+        }
+        if (sub_sizes) sub_sizes[j] = size;
+    }
+    uint64_t before = 0;
+    for (int src = 0; src < world; src++)
+        for (int b = 0; b < rank * sub; b++) before += m[(size_t)src * B + b];   // everything owned by lower ranks
+    if (n_out) *n_out = r;
+    if (global_offset) *global_offset = before;
+    return LSDSORT_OK;
+}
+
 int lsdsort_sharded_thresholds(const uint32_t* gathered, int world, int samples_per_rank, int rank, uint64_t* thresholds)
 {
-    if (!gathered || log2_world(world) < 0 || samples_per_rank < 1 || rank < 0 || rank >= world || (world > 1 && !thresholds))
+    return lsdsort_sharded_thresholds_parts(gathered, world, samples_per_rank, rank, world, thresholds);
+}
+
+int lsdsort_sharded_thresholds_parts(const uint32_t* gathered, int world, int samples_per_rank, int rank, int parts, uint64_t* thresholds)
+{
+    if (!gathered || log2_world(world) < 0 || samples_per_rank < 1 || rank < 0 || rank >= world || parts < 1 || parts > 8 ||
+        (parts > 1 && !thresholds))
         return LSDSORT_ERR_INVALID_ARG;
     // every sampled key as (key, source rank): equal keys are told apart by where they came from, so a run of one
     // value longer than a bucket can still be cut (between ranks), and the cut keeps the exchange stable
@@ -537,12 +599,12 @@ int lsdsort_sharded_thresholds(const uint32_t* gathered, int world, int samples_
     }
     std::sort(tuples.begin(), tuples.end());
     const size_t total = tuples.size();
-    for (int b = 1; b < world; b++) {
+    for (int b = 1; b < parts; b++) {
         if (total == 0) {   // nothing to sort anywhere: any rule does
             thresholds[b - 1] = 1ull << 32;
             continue;
         }
-        const uint64_t cut = tuples[(size_t)(((unsigned __int128)b * total) / world)];
+        const uint64_t cut = tuples[(size_t)(((unsigned __int128)b * total) / parts)];
         const uint64_t key = cut >> 8;
         const int from = (int)(cut & 0xFF);
         // (k, rank) >= (key, from)  <=>  k > key, or k == key and rank >= from  <=>  k >= key + (rank < from)
@@ -588,7 +650,10 @@ static int sharded_step(lsdsort_comm* c, const uint32_t* d_keys_in, size_t n_loc
     int dev = -1;
     SH_HIP(hipGetDevice(&dev));
     if (dev != c->device) return LSDSORT_ERR_INVALID_ARG;       // the communicator lives on the device it was made on
-    const int W = c->world, bits = log2_world(W);
+    const int W = c->world, S = c->sub_buckets, B = W * S;
+    int bits = 0;
+    while ((1 << bits) < B) bits++;
+    if (partition == LSDSORT_PARTITION_SPLITTERS && B > 8) return LSDSORT_ERR_UNSUPPORTED;   // the value partition cuts into eight at most
     const ShardedLayout L = make_sharded_layout(n_local, out_capacity, W, radix_bits);
     if (!d_workspace || (reinterpret_cast<uintptr_t>(d_workspace) & (kAlign - 1)) || workspace_bytes < L.total) return LSDSORT_ERR_WORKSPACE;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
@@ -596,70 +661,97 @@ static int sharded_step(lsdsort_comm* c, const uint32_t* d_keys_in, size_t n_loc
     uint64_t* d_vec = reinterpret_cast<uint64_t*>(ws + L.vec);
     uint64_t* d_all = reinterpret_cast<uint64_t*>(ws + L.all);
     uint32_t* d_send = reinterpret_cast<uint32_t*>(ws + L.send);
+    uint32_t* sticky = reinterpret_cast<uint32_t*>(ws + L.sticky);
     Transport& T = *c->transport;
+    SH_HIP(hipMemsetAsync(sticky, 0, sizeof(uint32_t), stream));
 
     // 0.  splitter rule only: a regular sample of every shard to every rank (one more host wait, ahead of the partition);
-    //     each rank then cuts the sorted (key, source rank) sample into W equal parts and derives ITS thresholds
+    //     each rank then cuts the sorted (key, source rank) sample into B equal parts and derives ITS thresholds
     uint64_t thresholds[8] = {};
     if (partition == LSDSORT_PARTITION_SPLITTERS) {
-        constexpr int S = LSDSORT_SPLITTER_SAMPLES;
+        constexpr int NS = LSDSORT_SPLITTER_SAMPLES;
         uint32_t* d_samp = reinterpret_cast<uint32_t*>(ws + L.samp);
         uint32_t* d_samp_all = reinterpret_cast<uint32_t*>(ws + L.samp_all);
-        SH_HIP(lsd::launch_sample_keys(d_keys_in, (uint32_t)n_local, (uint32_t)S, d_samp, stream));
+        SH_HIP(lsd::launch_sample_keys(d_keys_in, (uint32_t)n_local, (uint32_t)NS, d_samp, stream));
         SH_HIP(hipEventRecord(c->sample_ready, stream));
         SH_HIP(hipStreamWaitEvent(c->side, c->sample_ready, 0));
-        SH_TRY(T.all_gather(d_samp, d_samp_all, (size_t)(1 + S) * sizeof(uint32_t), c->side));
-        SH_HIP(hipMemcpyAsync(c->h_samples, d_samp_all, (size_t)W * (1 + S) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->side));
+        SH_TRY(T.all_gather(d_samp, d_samp_all, (size_t)(1 + NS) * sizeof(uint32_t), c->side));
+        SH_HIP(hipMemcpyAsync(c->h_samples, d_samp_all, (size_t)W * (1 + NS) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->side));
         SH_HIP(hipStreamSynchronize(c->side));
-        SH_TRY(lsdsort_sharded_thresholds(c->h_samples, W, S, c->rank, thresholds));
+        SH_TRY(lsdsort_sharded_thresholds_parts(c->h_samples, W, NS, c->rank, B, thresholds));
     }
 
-    // 1 + 2.  main stream: counts, EVENT, partition pass.  side stream: count exchange while the partition runs.
+    // 1 + 2.  main stream: counts, EVENT, partition pass into B buckets (destination rank b / S, its sub-bucket b % S).
+    //         side stream: count exchange while the partition runs.
     if (partition == LSDSORT_PARTITION_SPLITTERS)
         SH_TRY(lsd::threshold_partition_with_event(d_keys_in, d_send, n_local, bits, thresholds, d_vec, ws + L.part_ws, L.part_ws_bytes,
                                                    stream, c->counts_ready));
     else
         SH_TRY(lsd::partition_with_event(d_keys_in, d_send, n_local, bits, d_vec, ws + L.part_ws, L.part_ws_bytes, stream, c->counts_ready));
     SH_HIP(hipStreamWaitEvent(c->side, c->counts_ready, 0));
-    SH_HIP(lsd::launch_store_u64(d_vec + W, (uint64_t)out_capacity, c->side));
-    SH_TRY(T.all_gather(d_vec, d_all, (size_t)(W + 1) * sizeof(uint64_t), c->side));
-    SH_HIP(hipMemcpyAsync(c->h_all, d_all, (size_t)W * (W + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->side));
+    SH_HIP(lsd::launch_store_u64(d_vec + B, (uint64_t)out_capacity, c->side));
+    SH_TRY(T.all_gather(d_vec, d_all, (size_t)(B + 1) * sizeof(uint64_t), c->side));
+    SH_HIP(hipMemcpyAsync(c->h_all, d_all, (size_t)W * (B + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->side));
     SH_HIP(hipStreamSynchronize(c->side));                      // the step's only host wait
 
     // host: the plan, identical on every rank; so is the verdict on everybody's capacity
-    uint64_t m[64], send_off[8], recv_off[8], total = 0, offset = 0;
+    uint64_t m[8 * kMaxBuckets], send_off[kMaxBuckets], recv_off[4 * 8], sub_size[4], total = 0, offset = 0;
     bool fits = true;
     for (int src = 0; src < W; src++)
-        for (int dst = 0; dst < W; dst++) m[src * W + dst] = c->h_all[(size_t)src * (W + 1) + dst];
+        for (int b = 0; b < B; b++) m[src * B + b] = c->h_all[(size_t)src * (B + 1) + b];
     for (int dst = 0; dst < W; dst++) {
         uint64_t recv = 0;
-        for (int src = 0; src < W; src++) recv += m[src * W + dst];
-        if (recv > c->h_all[(size_t)dst * (W + 1) + W]) fits = false;
+        for (int src = 0; src < W; src++)
+            for (int j = 0; j < S; j++) recv += m[src * B + dst * S + j];
+        if (recv > c->h_all[(size_t)dst * (B + 1) + B]) fits = false;
     }
-    SH_TRY(lsdsort_sharded_plan(m, W, c->rank, send_off, recv_off, &total, &offset));
-    if (counts_matrix) std::memcpy(counts_matrix, m, (size_t)W * W * sizeof(uint64_t));
+    SH_TRY(lsdsort_sharded_plan_sub(m, W, S, c->rank, send_off, recv_off, sub_size, &total, &offset));
+    if (counts_matrix)                                          // [src][dst], whole ranks
+        for (int src = 0; src < W; src++)
+            for (int dst = 0; dst < W; dst++) {
+                uint64_t sum = 0;
+                for (int j = 0; j < S; j++) sum += m[src * B + dst * S + j];
+                counts_matrix[src * W + dst] = sum;
+            }
     *n_out = (size_t)total;
     *global_offset = offset;
     if (!fits) return LSDSORT_ERR_CAPACITY;                    // every rank returns this, none has posted a send
 
-    // 3.  one grouped exchange, every peer at once; my own bucket stays on the device.  The group is closed whatever
-    //     happens inside it (an open RCCL group would swallow every later call of this thread); group_end reports the
-    //     first error of the group.
-    SH_TRY(T.group_start());
-    for (int step = 1; step < W; step++) {
-        const int to = (c->rank + step) % W, from = (c->rank - step + W) % W;   // a different partner pair per step
-        const uint64_t ns = m[c->rank * W + to], nr = m[from * W + c->rank];
-        if (ns && T.send(d_send + send_off[to], (size_t)ns * sizeof(uint32_t), to, stream) != LSDSORT_OK) break;
-        if (nr && T.recv(d_out + recv_off[from], (size_t)nr * sizeof(uint32_t), from, stream) != LSDSORT_OK) break;
+    // 3 + 4.  Per sub-bucket j: one grouped exchange, every peer at once (my own part stays on the device), then its local
+    //         sort -- on the `sorter` stream, so that sub-bucket j is being sorted while j + 1 is still on the links (a rank's
+    //         sub-buckets are consecutive key ranges: sorted one by one they are the sorted slice).  A group is closed whatever
+    //         happens inside it (an open RCCL group would swallow every later call of this thread); group_end reports the
+    //         first error of the group.
+    uint64_t sub_begin = 0;
+    for (int j = 0; j < S; j++) {
+        SH_TRY(T.group_start());
+        for (int step = 1; step < W; step++) {
+            const int to = (c->rank + step) % W, from = (c->rank - step + W) % W;   // a different partner pair per step
+            const uint64_t ns = m[c->rank * B + to * S + j], nr = m[from * B + c->rank * S + j];
+            if (ns && T.send(d_send + send_off[to * S + j], (size_t)ns * sizeof(uint32_t), to, stream) != LSDSORT_OK) break;
+            if (nr && T.recv(d_out + recv_off[j * W + from], (size_t)nr * sizeof(uint32_t), from, stream) != LSDSORT_OK) break;
+        }
+        SH_TRY(T.group_end(stream));
+        const uint64_t mine = m[c->rank * B + c->rank * S + j];
+        if (mine)
+            SH_HIP(hipMemcpyAsync(d_out + recv_off[j * W + c->rank], d_send + send_off[c->rank * S + j], (size_t)mine * sizeof(uint32_t),
+                                  hipMemcpyDeviceToDevice, stream));
+        // the local LSD passes of what has arrived (the top bits are constant within a sub-bucket; all 32 bits are still sorted)
+        hipStream_t sort_on = S > 1 ? c->sorter : stream;
+        if (S > 1) {
+            SH_HIP(hipEventRecord(c->arrived[j], stream));
+            SH_HIP(hipStreamWaitEvent(c->sorter, c->arrived[j], 0));
+        }
+        if (sub_size[j] == 0) SH_HIP(hipMemsetAsync(ws + L.sort_ws, 0, sizeof(uint32_t), sort_on));   // an empty sort never touches its fault word
+        SH_TRY(lsdsort_u32_device(d_out + sub_begin, ws + L.sort_ws, L.sort_ws_bytes, (size_t)sub_size[j], radix_bits, sort_on));
+        SH_HIP(lsd::launch_keep_fault(sticky, reinterpret_cast<const uint32_t*>(ws + L.sort_ws), sort_on));
+        sub_begin += sub_size[j];
     }
-    SH_TRY(T.group_end(stream));
-    const uint64_t mine = m[c->rank * W + c->rank];
-    if (mine)
-        SH_HIP(hipMemcpyAsync(d_out + recv_off[c->rank], d_send + send_off[c->rank], (size_t)mine * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-
-    // 4.  the local LSD passes (the top bits are constant within a rank; all 32 bits are still sorted)
-    if (total == 0) SH_HIP(hipMemsetAsync(ws + L.sort_ws, 0, sizeof(uint32_t), stream));   // an empty sort never touches its fault word
-    return lsdsort_u32_device(d_out, ws + L.sort_ws, L.sort_ws_bytes, (size_t)total, radix_bits, stream);
+    if (S > 1) {   // the caller's stream sees the step complete
+        SH_HIP(hipEventRecord(c->sorted_all, c->sorter));
+        SH_HIP(hipStreamWaitEvent(stream, c->sorted_all, 0));
+    }
+    return LSDSORT_OK;
 }
 
 int lsdsort_sharded_check_device(void* d_workspace, size_t n_local, size_t out_capacity, int world, int radix_bits, void* hip_stream)
@@ -668,7 +760,9 @@ int lsdsort_sharded_check_device(void* d_workspace, size_t n_local, size_t out_c
     if (log2_world(world) < 0 || lsdsort_workspace_bytes(1, radix_bits, 0) == 0) return LSDSORT_ERR_INVALID_ARG;
     const ShardedLayout L = make_sharded_layout(n_local, out_capacity, world, radix_bits);
     int status = lsdsort_check_device(static_cast<char*>(d_workspace) + L.part_ws, hip_stream);   // the partition pass is chained too
-    if (status == LSDSORT_OK) status = lsdsort_check_device(static_cast<char*>(d_workspace) + L.sort_ws, hip_stream);
+    // the local sorts' fault words, kept in the sticky word (the sorts share a workspace; lsdsort_check_device reads the first
+    // word of what it is given)
+    if (status == LSDSORT_OK) status = lsdsort_check_device(static_cast<char*>(d_workspace) + L.sticky, hip_stream);
     return status;
 }
 

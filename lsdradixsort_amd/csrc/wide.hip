@@ -68,12 +68,6 @@ __global__ void __launch_bounds__(kThreads) merge_u64_kernel(const uint32_t* __r
         out[i] = make_uint2(lo[i], hi[i]);
 }
 
-// sticky[0] |= fault[0] (one thread; stream-ordered behind the sort whose fault word it keeps)
-__global__ void keep_fault_kernel(uint32_t* sticky, const uint32_t* fault)
-{
-    if (*fault) *sticky |= *fault;
-}
-
 struct WideLayout {
     size_t sticky = 0;              // u32: fault words of every sort inside the call, ORed together (each sort's opening
                                     // memset clears the shared sort workspace's own word, so the first sort's would be lost)
@@ -151,9 +145,9 @@ int lsdsort_u64_device(uint64_t* d_keys, void* d_workspace, size_t workspace_byt
     W_HIP(hipGetLastError());
     // low word first, then a stable sort on the high word: sorted by (hi, lo) -- the LSD argument, one word at a time
     W_TRY(lsdsort_pairs_u32_device(lo, hi, ws + L.sort_ws, L.sort_ws_bytes, n, radix_bits, s));
-    hipLaunchKernelGGL(keep_fault_kernel, dim3(1), dim3(1), 0, s, sticky, fault);   // the next sort's memset clears that word
+    W_HIP(lsd::launch_keep_fault(sticky, fault, s));   // the next sort's memset clears that word
     W_TRY(lsdsort_pairs_u32_device(hi, lo, ws + L.sort_ws, L.sort_ws_bytes, n, radix_bits, s));
-    hipLaunchKernelGGL(keep_fault_kernel, dim3(1), dim3(1), 0, s, sticky, fault);
+    W_HIP(lsd::launch_keep_fault(sticky, fault, s));
     hipLaunchKernelGGL(merge_u64_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, lo, hi, reinterpret_cast<uint2*>(d_keys), n);
     W_HIP(hipGetLastError());
     return LSDSORT_OK;
@@ -196,7 +190,7 @@ int lsdsort_records_device(void* d_keys, void* d_vals, int key_bits, int val_bit
         pay[np++] = vlo;
         if (vhi) pay[np++] = vhi;
         W_TRY(lsdsort_multi_u32_device(klo, pay, np, ws + L.sort_ws, L.sort_ws_bytes, n, radix_bits, s));
-        hipLaunchKernelGGL(keep_fault_kernel, dim3(1), dim3(1), 0, s, sticky, fault);
+        W_HIP(lsd::launch_keep_fault(sticky, fault, s));
     }
     if (khi) {
         uint32_t* pay[3];
@@ -205,7 +199,7 @@ int lsdsort_records_device(void* d_keys, void* d_vals, int key_bits, int val_bit
         pay[np++] = vlo;
         if (vhi) pay[np++] = vhi;
         W_TRY(lsdsort_multi_u32_device(khi, pay, np, ws + L.sort_ws, L.sort_ws_bytes, n, radix_bits, s));
-        hipLaunchKernelGGL(keep_fault_kernel, dim3(1), dim3(1), 0, s, sticky, fault);
+        W_HIP(lsd::launch_keep_fault(sticky, fault, s));
         hipLaunchKernelGGL(merge_u64_kernel, dim3(g), dim3(kThreads), 0, s, klo, khi, static_cast<uint2*>(d_keys), n);
         W_HIP(hipGetLastError());
     }

@@ -91,7 +91,7 @@ class ShardedSorter:
 
     PARTITIONS = {"msb": 0, "splitters": 1}     # LSDSORT_PARTITION_MSB / LSDSORT_PARTITION_SPLITTERS
 
-    def __init__(self, radix_bits: int = 8, group=None, slack: float = 0.25, partition: str = "msb"):
+    def __init__(self, radix_bits: int = 8, group=None, slack: float = 0.25, partition: str = "msb", sub_buckets: int = 1):
         import ctypes
 
         import torch
@@ -141,6 +141,8 @@ class ShardedSorter:
             local = int(t.item())
         check(local, "lsdsort_prepare_device (some rank)")
         check(L.lsdsort_comm_create(ident, self.world, self.rank, ctypes.byref(handle)), "lsdsort_comm_create")
+        # sub-bucket pipelining (the exchange of sub-bucket j + 1 under the local sort of j): the same value on every rank
+        check(L.lsdsort_comm_set_sub_buckets(handle, sub_buckets), "lsdsort_comm_set_sub_buckets")
         self._comm = handle
         self._ws = None
         self._out = None
@@ -295,7 +297,7 @@ class LoopbackWorld:
 
     PARTITIONS = ShardedSorter.PARTITIONS
 
-    def __init__(self, world: int, radix_bits: int = 8):
+    def __init__(self, world: int, radix_bits: int = 8, sub_buckets: int = 1):
         import ctypes
 
         from . import api
@@ -308,6 +310,8 @@ class LoopbackWorld:
         handles = (ctypes.c_void_p * world)()
         check(api.lib().lsdsort_comm_create_loopback(world, handles), "lsdsort_comm_create_loopback")
         self._comms = [ctypes.c_void_p(h) for h in handles]
+        for c in self._comms:      # sub-bucket pipelining: a collective setting, the same on every rank
+            check(api.lib().lsdsort_comm_set_sub_buckets(c, sub_buckets), "lsdsort_comm_set_sub_buckets")
         self.last = [None] * world      # (workspace tensor, n_local, capacity) of each rank's last step
 
     def close(self):

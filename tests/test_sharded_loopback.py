@@ -43,10 +43,10 @@ def _shards(kind, W, seed):
     return out
 
 
-def _run(gpu, world, shards, partition, capacities=None, radix_bits=8):
+def _run(gpu, world, shards, partition, capacities=None, radix_bits=8, sub_buckets=1):
     from lsdradixsort_amd.dist import LoopbackWorld
 
-    lw = LoopbackWorld(world, radix_bits)
+    lw = LoopbackWorld(world, radix_bits, sub_buckets)
     try:
         dev = [gpu.to_device(s) for s in shards]
         res = lw.step(dev, capacities=capacities, partition=partition)
@@ -141,3 +141,43 @@ def test_host_entry_with_virtual_gpus(gpu, oracle_mod, virtual_gpus):
     few = np.array([5, 3, 9], dtype=np.uint32)             # fewer keys than ranks: empty shards
     assert L.lsdsort_u32_loopback(few.ctypes.data, 3, 8, virtual_gpus) == 0 and list(few) == [3, 5, 9]
     assert L.lsdsort_u32_loopback(few.ctypes.data, 3, 8, 3) == -1    # not a power of two
+
+
+@pytest.mark.parametrize("world,sub,partition", [(2, 2, "msb"), (2, 4, "msb"), (4, 2, "msb"), (4, 4, "msb"), (8, 2, "msb"),
+                                                 (2, 2, "splitters"), (2, 4, "splitters"), (4, 2, "splitters")])
+def test_sub_bucket_pipelining(gpu, world, sub, partition):
+    """Sub-bucket pipelining (lsdsort_comm_set_sub_buckets): every rank's key range cut into `sub` consecutive sub-ranges,
+    exchanged one grouped exchange after the other, each sorted on the communicator's internal stream while the next is
+    exchanged; world x sub = 16 takes the 4-bit partition kernels.  Same checks as the plain step: the rank-order
+    concatenation is the sorted union, offsets and counts agree, shards untouched, fault words clean."""
+    for kind in ("uniform", "dead_top_bits", "all_equal", "all_ones", "heavy_value", "presorted_shards"):
+        shards = _shards(kind, world, 31 * world + sub + len(kind))
+        union = np.sort(np.concatenate(shards))
+        res, dev = _run(gpu, world, shards, partition, sub_buckets=sub)
+        pieces, expect_offset = [], 0
+        for r, (st, out, n_out) in enumerate(res):
+            assert st == 0, (kind, world, sub, partition, r, st)
+            assert out.global_offset == expect_offset
+            assert int(out.counts[:, r].sum()) == n_out
+            pieces.append(gpu.to_host(out.keys))
+            expect_offset += n_out
+        assert np.array_equal(np.concatenate(pieces), union), (kind, world, sub, partition)
+        for r, d in enumerate(dev):
+            assert np.array_equal(gpu.to_host(d), shards[r]), (kind, r)
+
+
+def test_sub_bucket_argument_checks(gpu):
+    from lsdradixsort_amd import errors
+    from lsdradixsort_amd.dist import LoopbackWorld
+
+    with pytest.raises(Exception):
+        LoopbackWorld(8, 8, 4)                      # 8 x 4 = 32 buckets: more than the partition pass takes
+    with pytest.raises(Exception):
+        LoopbackWorld(2, 8, 3)
+    lw = LoopbackWorld(8, 8, 2)                     # 16 buckets: fine by bit field, refused by value (seven splitters at most)
+    try:
+        shards = _shards("uniform", 8, 9)
+        res = lw.step([gpu.to_device(s) for s in shards], partition="splitters", timeout=60.0)
+        assert all(st in (errors.LSDSORT_ERR_UNSUPPORTED, errors.LSDSORT_ERR_COMM) for st, _, _ in res), [st for st, _, _ in res]
+    finally:
+        lw.close()
