@@ -171,9 +171,11 @@ typedef struct lsdsort_timing {
     float scan_ms;        /* stage 2 (digit-count scan / tile offset tables)                */
     float scatter_ms[LSDSORT_MAX_PASSES]; /* stage 3, one entry per pass (chained form: the  */
                                           /* kernel's own begin/end, hipExtLaunchKernel)    */
-    int passes;
+    int passes;           /* global passes that ran (hybrid form: 2)                          */
     int tile_keys;        /* keys per rank-and-scatter tile                                 */
     int tiles;
+    int hybrid;           /* 1: the hybrid form ran (two global passes + the local stage)    */
+    float local_ms;       /* hybrid form: the local stage (every bucket finished in LDS)     */
 } lsdsort_timing;
 LSDSORT_API int lsdsort_u32_device_timed(uint32_t* d_keys, uint32_t* d_vals, void* d_workspace,
                                          size_t workspace_bytes, size_t n, int radix_bits,
@@ -209,6 +211,14 @@ LSDSORT_API int lsdsort_rank_scatter_u32_device(const uint32_t* d_in, uint32_t* 
                                                 const uint32_t* d_vals_in, uint32_t* d_vals_out,
                                                 const uint32_t* d_global, size_t n, int radix_bits,
                                                 int bit_group, void* hip_stream);
+
+/* The hybrid form's local stage on its own (lsdradixsort_amd/csrc/local_sort.hip): bucket b = d_keys[d_bases[b] .. d_bases[b + 1])
+ * (num_buckets + 1 ascending device words) is sorted IN PLACE by its keys' low `low_bits` bits (1..27; stable LSD passes of at
+ * most nine bits each, run from LDS to LDS by one workgroup per bucket).  Buckets of more than 16384 keys are left as they are
+ * (inside a whole sort the planner has ruled them out).  Needs the returning-LDS-add rank form (LSDSORT_ERR_UNSUPPORTED where the
+ * device probe failed). */
+LSDSORT_API int lsdsort_local_sort_u32_device(uint32_t* d_keys, const uint32_t* d_bases, size_t num_buckets, int low_bits,
+                                              void* hip_stream);
 
 /* One read of all keys -> all 32/radix_bits digit histograms, d_hist[g][d] (uint32). */
 LSDSORT_API int lsdsort_digit_histograms_u32_device(const uint32_t* d_keys, size_t n, int radix_bits,
@@ -368,6 +378,15 @@ LSDSORT_API int lsdsort_set_xcd_chunk(int chunk);
  * capturable, results identical.  On by default for the uint32 sorts (keys and pairs, default algorithm); the typed
  * sorts and 1-bit digits always run every pass.  0 switches it off (every pass runs, as the reference's do). */
 LSDSORT_API int lsdsort_set_pass_skipping(int on);
+/* The hybrid form (lsdradixsort_amd/csrc/hybrid.hip, local_sort.hip; no reference counterpart -- its every pass goes through
+ * global memory, .cu:844-905).  Keys-only sorts with 8-bit digits of 2^27 .. 4.8e8 keys: the two HIGH digits are sorted first
+ * by two ordinary global passes (LSD order: bits 16-23, then 24-31), which leaves the array sorted by its top 16 bits; every
+ * bucket of equal top-15-bit value (2^15 of them) is then finished inside one CU's LDS (bits 0-8, then 9-16) and stored once:
+ * 4 + 8 + 8 + 8 = 28 bytes per key of memory traffic instead of 4 + 4 x 8 = 36.  Valid only if every bucket fits the local stage
+ * (16384 keys), which depends on the keys: the upfront read counts the buckets exactly and the DEVICE decides before a key is
+ * moved; otherwise the ordinary four global passes run (after their own upfront read: such keys pay about 10 % for the
+ * attempt).  Same result either way.  On by default; 0 = always the four global passes, as the reference's structure. */
+LSDSORT_API int lsdsort_set_hybrid(int on);
 /* Runtime tuning knob for experiments: selects among the compiled tile shapes (see
  * DESIGN.md); -1 restores the default.  Returns LSDSORT_ERR_INVALID_ARG if unknown. */
 LSDSORT_API int lsdsort_set_tile_config(int radix_bits, int config_id);

@@ -51,6 +51,8 @@ class LsdsortTiming(ctypes.Structure):
         ("passes", ctypes.c_int),
         ("tile_keys", ctypes.c_int),
         ("tiles", ctypes.c_int),
+        ("hybrid", ctypes.c_int),
+        ("local_ms", ctypes.c_float),
     ]
 
 
@@ -82,6 +84,7 @@ SIGNATURES = {
     "lsdsort_tile_offsets_u32_device": (c_int, [c_u32p, c_u32p, c_u32p, c_size, c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "lsdsort_rank_scatter_u32_device": (c_int, [c_u32p, c_u32p, c_u32p, c_u32p, c_u32p, c_size, c_int, c_int,
                                                 ctypes.c_void_p]),
+    "lsdsort_local_sort_u32_device": (c_int, [c_u32p, c_u32p, c_size, c_int, ctypes.c_void_p]),
     "lsdsort_digit_histograms_u32_device": (c_int, [c_u32p, c_size, c_int, c_u32p, ctypes.c_void_p]),
     "lsdsort_msb_partition_workspace_bytes": (c_size, [c_size, c_int]),
     "lsdsort_msb_partition_u32_device": (c_int, [c_u32p, c_u32p, c_size, c_int, ctypes.c_void_p, ctypes.c_void_p,
@@ -123,6 +126,7 @@ SIGNATURES = {
     "lsdsort_prepare_device": (c_int, []),
     "lsdsort_set_xcd_chunk": (c_int, [c_int]),
     "lsdsort_set_pass_skipping": (c_int, [c_int]),
+    "lsdsort_set_hybrid": (c_int, [c_int]),
     "lsdsort_set_rank_method": (c_int, [c_int]),
     "lsdsort_rank_method": (c_int, [c_int]),
 }

@@ -19,7 +19,7 @@ from .errors import LSDSORT_ALGO_ONESWEEP, LSDSORT_ALGO_STAGED, check
 __all__ = [
     "sort", "sort_pairs", "to_device", "to_host", "workspace_bytes", "GPULSDRadixSort",
     "GPULSDRadixSortTimed", "BuildHistograms", "BuildOffsets", "RankScatter", "DigitHistograms",
-    "MSBPartition", "SplitterPartition", "GPUSortTyped", "GPUSortWide", "GPUSortMulti", "tile_keys", "set_tile_config", "set_rank_method", "rank_method", "set_xcd_chunk", "LSDSORT_ALGO_ONESWEEP", "LSDSORT_ALGO_STAGED",
+    "MSBPartition", "SplitterPartition", "GPUSortTyped", "GPUSortWide", "GPUSortMulti", "set_hybrid", "tile_keys", "set_tile_config", "set_rank_method", "rank_method", "set_xcd_chunk", "LSDSORT_ALGO_ONESWEEP", "LSDSORT_ALGO_STAGED",
 ]
 
 
@@ -112,6 +112,12 @@ def set_tile_config(radix_bits: int, config_id: int) -> None:
 def set_xcd_chunk(chunk: int) -> None:
     """Consecutive tiles kept on one XCD by the rank-and-scatter kernel (0 = off; speed only)."""
     check(lib().lsdsort_set_xcd_chunk(chunk), "lsdsort_set_xcd_chunk")
+
+
+def set_hybrid(on: bool) -> None:
+    """The hybrid form of large keys-only 8-bit sorts (two global passes + an LDS-resident local stage, decided on the
+    device; ``lsdsort_set_hybrid``).  Default on; off = always the four global passes."""
+    check(lib().lsdsort_set_hybrid(1 if on else 0), "lsdsort_set_hybrid")
 
 
 def set_pass_skipping(on: bool) -> None:
@@ -270,7 +276,7 @@ def GPULSDRadixSortTimed(d_keys, r: int = 8, d_vals=None, algorithm: int = LSDSO
     return {
         "total_ms": t.total_ms, "clear_ms": t.clear_ms, "histogram_ms": t.histogram_ms, "scan_ms": t.scan_ms,
         "scatter_ms": [t.scatter_ms[i] for i in range(t.passes)], "passes": t.passes, "tile_keys": t.tile_keys,
-        "tiles": t.tiles,
+        "tiles": t.tiles, "hybrid": t.hybrid, "local_ms": t.local_ms,
     }
 
 

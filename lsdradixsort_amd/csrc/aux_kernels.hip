@@ -266,8 +266,9 @@ template <int R, int THREADS, bool WIDE = false, bool DMA = false>
 __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                   uint32_t region0_keys, uint32_t* __restrict__ joint,
                                                                   uint32_t vec_chunks, const KeyTransform xf,
-                                                                  uint32_t first_key)
+                                                                  uint32_t first_key, const uint32_t* __restrict__ skip)
 {
+    if (skip && *skip != 0u) return;   // uniform: the hybrid form took the sort (hybrid.hip)
     // `keys` may be a slice [first_key, first_key + n) of the array being sorted (the host entry counts each chunk as
     // it arrives over PCIe): pass-0 regions are by position in the WHOLE array; first_key is a multiple of the chunk.
     const uint32_t chunk_base = first_key / (uint32_t)(THREADS * 4);
@@ -653,7 +654,7 @@ __global__ void __launch_bounds__(THREADS) joint_histograms_kernel(const uint32_
 
 template <int R, int THREADS, bool WIDE = false, bool DMA = (LSD_HIST_DMA != 0)>
 static hipError_t launch_joint_inst(const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* joint,
-                                    hipStream_t stream, const KeyTransform& xf, uint32_t first_key)
+                                    hipStream_t stream, const KeyTransform& xf, uint32_t first_key, const uint32_t* skip)
 {
     constexpr int P = 32 / R;
     constexpr int F = (1 << R) << region_bits_for_radix(R);
@@ -679,20 +680,20 @@ static hipError_t launch_joint_inst(const uint32_t* keys, uint32_t n, uint32_t r
     const uint32_t cap = (uint32_t)(LSD_HIST_GRID_WAVES * 64 / THREADS);   // enough waves to cover HBM latency (512 workgroups of 1024 threads)
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds_bytes, stream, keys, n, region0_keys, joint, vec_chunks, xf, first_key);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds_bytes, stream, keys, n, region0_keys, joint, vec_chunks, xf, first_key, skip);
     return hipGetLastError();
 }
 
 hipError_t launch_joint_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys,
-                                   uint32_t* joint, hipStream_t stream, const KeyTransform& xf, uint32_t first_key)
+                                   uint32_t* joint, hipStream_t stream, const KeyTransform& xf, uint32_t first_key, const uint32_t* skip)
 {
     switch (radix_bits) {
 #ifdef LSD_R4_NARROW_HIST
-        case 4: return launch_joint_inst<4, 256>(keys, n, region0_keys, joint, stream, xf, first_key);
+        case 4: return launch_joint_inst<4, 256>(keys, n, region0_keys, joint, stream, xf, first_key, skip);
 #else
-        case 4: return launch_joint_inst<4, LSD_R4_HIST_THREADS, true>(keys, n, region0_keys, joint, stream, xf, first_key);   // 64 KiB of counters per workgroup
+        case 4: return launch_joint_inst<4, LSD_R4_HIST_THREADS, true>(keys, n, region0_keys, joint, stream, xf, first_key, skip);   // 64 KiB of counters per workgroup
 #endif
-        case 8: return launch_joint_inst<8, (LSD_R8_REGION_BITS == 3 ? LSD_R8_HIST_THREADS3 : LSD_R8_HIST_THREADS)>(keys, n, region0_keys, joint, stream, xf, first_key);   // 32 / 64 / 128 KiB of counters per workgroup at 3 / 4 / 5 bits
+        case 8: return launch_joint_inst<8, (LSD_R8_REGION_BITS == 3 ? LSD_R8_HIST_THREADS3 : LSD_R8_HIST_THREADS)>(keys, n, region0_keys, joint, stream, xf, first_key, skip);   // 32 / 64 / 128 KiB of counters per workgroup at 3 / 4 / 5 bits
         default: return hipErrorInvalidValue;
     }
 }
@@ -708,13 +709,22 @@ template <int REG>
 __global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __restrict__ counts, int bins, uint32_t n,
                                                           uint32_t tile_keys, uint32_t region0_keys, int passes,
                                                           uint32_t* __restrict__ tables, uint32_t table_words,
-                                                          uint32_t* __restrict__ plan, uint32_t* __restrict__ fault)
+                                                          uint32_t* __restrict__ plan, uint32_t* __restrict__ fault,
+                                                          const uint32_t* __restrict__ hybrid_ok)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base[257];
     __shared__ uint32_t s_const[kPlanWords];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const int pass = blockIdx.x;
+    if (hybrid_ok && *hybrid_ok != 0u) {   // uniform: the hybrid form runs; these passes leave at once and touch nothing (2)
+        if (plan && tid == 0) {
+            plan[2 * pass] = 2u;
+            plan[2 * pass + 1] = 0u;
+            if (pass + 1 == passes) plan[2 * passes] = 0u;   // the local stage leaves the keys in the caller's buffer
+        }
+        return;
+    }
     // This kernel is latency, not work: a small sort spends 5 of its 50 us here (rocprofv3, 2^20 keys, round 3).  So every
     // global load it needs is requested up front, in one window: this pass's counts first ...
     const uint32_t* c = counts + (size_t)pass * bins * REG;
@@ -832,7 +842,7 @@ hipError_t launch_finish_plan(const uint32_t* plan_final, uint32_t* keys, const 
 
 hipError_t launch_scan_regions(int radix_bits, int passes, int regions, const uint32_t* counts, uint32_t n,
                                uint32_t tile_keys, uint32_t region0_keys, uint32_t* tables, hipStream_t stream, uint32_t* plan,
-                               uint32_t* fault)
+                               uint32_t* fault, const uint32_t* hybrid_ok)
 {
     if (radix_bits < 1 || radix_bits > 8 || (regions != 1 && regions != regions_for_radix(radix_bits))) return hipErrorInvalidValue;
     if (plan && 2 * passes + 1 > kPlanWords) return hipErrorInvalidValue;
@@ -840,16 +850,16 @@ hipError_t launch_scan_regions(int radix_bits, int passes, int regions, const ui
     const uint32_t words = (uint32_t)region_table_words(radix_bits);
     if (regions == 1)
         hipLaunchKernelGGL((scan_regions_kernel<1>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
-                           region0_keys, passes, tables, words, plan, fault);
+                           region0_keys, passes, tables, words, plan, fault, hybrid_ok);
     else if (regions == 8)
         hipLaunchKernelGGL((scan_regions_kernel<8>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
-                           region0_keys, passes, tables, words, plan, fault);
+                           region0_keys, passes, tables, words, plan, fault, hybrid_ok);
     else if (regions == 16)
         hipLaunchKernelGGL((scan_regions_kernel<16>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
-                           region0_keys, passes, tables, words, plan, fault);
+                           region0_keys, passes, tables, words, plan, fault, hybrid_ok);
     else
         hipLaunchKernelGGL((scan_regions_kernel<32>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
-                           region0_keys, passes, tables, words, plan, fault);
+                           region0_keys, passes, tables, words, plan, fault, hybrid_ok);
     return hipGetLastError();
 }
 

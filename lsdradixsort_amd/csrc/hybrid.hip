@@ -1,0 +1,261 @@
+// hybrid.hip -- stage 1 and the planner of the HYBRID form of the 8-bit-digit sort (keys only, 2^27 <= n < 2^29).
+//
+// The reference moves every key through global memory once per digit (GPULSDRadixSort, LSDRadixSort.cu:844-905: four passes at
+// 8-bit digits), and so does this library's chained form: 4 + 4 x 8 = 36 B/key.  An MI355X CU has 160 KiB of LDS: a bucket of
+// 16384 keys fits it, and the two LOW digits of such a bucket can be sorted without leaving the CU.  The hybrid form therefore
+// runs the two HIGH digits first, as ordinary chained passes (bits 16-23, then 24-31: LSD order, so the array ends up sorted by
+// its top 16 bits), and finishes the 2^15 buckets of equal top-15-bit value in LDS (local_sort.hip: bits 0-8, then 9-16):
+//
+//     one read (counts) + 2 global passes + 1 local stage = 4 + 8 + 8 + 8 = 28 B/key, and the local stage has no chained scan.
+//
+// It is only valid if EVERY bucket fits the local stage, which depends on the keys -- so it is decided on the device, exactly,
+// before anything is moved: the upfront read counts the top-15-bit buckets (32768 counters, 128 KiB of LDS per workgroup)
+// next to the first pass's (position region, digit) field, and the planner (one workgroup) takes the hybrid form iff the
+// largest bucket holds at most kLocalSortCap keys.  Otherwise every hybrid kernel returns at once and the ordinary form runs
+// (its own upfront read included: skewed keys pay 0.2 ms for the attempt).  Either way the result is the sorted array; which
+// form ran is visible in the workspace (lsdsort_timing.hybrid).
+//
+// Same stable rank, same kernels for the global passes; nothing here is derived from the reference's kernels.
+#include "lsd_device.hpp"
+#include "lsd_kernels.hpp"
+
+namespace lsd {
+
+constexpr int kHybridHistThreads = 1024;
+constexpr int kHybridCopiesA = 2;          // lane-class copies of the first pass's 2048 (region, digit) counters
+constexpr int kHybridVpt = 4;              // 16-byte vectors per thread per group
+
+// Upfront read of the hybrid form.  fieldA[(digit of bits 16-23) * 8 + position region] and bucket[key >> 17] (global, zero on
+// entry) receive the counts.  Grid-stride over chunks of 4096 keys, two register buffers, non-temporal loads (as stage 1 of the
+// ordinary form, aux_kernels.hip).  Heavy values are handled as there, in the two shapes that matter for THESE fields: keys equal
+// to a sticky candidate value (zeros, a default value) are counted by ballot, and a vector whose 256 keys agree on their bucket
+// (sorted or constant input) adds once per wave.
+__global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                                               uint32_t region0_keys, uint32_t* __restrict__ field_a,
+                                                                               uint32_t* __restrict__ bucket, uint32_t vec_chunks)
+{
+    constexpr int T = kHybridHistThreads, CA = kHybridCopiesA, VPT = kHybridVpt;
+    constexpr uint32_t FA = 2048, NB = kHybridBuckets;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
+    uint32_t* const s_a = s_mem;                 // [region][digit][CA], region-major: a wave's lanes share the region
+    uint32_t* const s_b = s_mem + FA * CA;       // [NB]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, copy = tid & (CA - 1);
+    for (uint32_t j = tid; j < FA * CA + NB; j += T) s_mem[j] = 0;
+    __syncthreads();
+
+    auto slot_a = [&](uint32_t k, uint32_t region0) -> uint32_t { return ((region0 << 8) | ((k >> 16) & 0xFFu)) * CA; };
+    auto count_plain = [&](uint32_t k, uint32_t region0) {
+        atomicAdd(&s_a[slot_a(k, region0) + copy], 1u);
+        atomicAdd(&s_b[k >> kHybridBucketShift], 1u);
+    };
+    uint32_t key1 = 0, key2 = 0;   // sticky heavy-key candidates (uniform)
+    bool have1 = false, have2 = false;
+    auto count_group = [&](uint32_t c, uint4 (&v)[VPT]) {
+        // heavy keys: see joint_histograms_kernel (aux_kernels.hip)
+        {
+            const uint32_t k0 = v[0].x;
+            const uint32_t n1 = (uint32_t)__builtin_popcountll(__ballot(k0 == key1));
+            if (!have1 || n1 < 16u) {
+                have1 = have2 = false;
+                const uint32_t a = __builtin_amdgcn_readfirstlane(k0);
+                unsigned long long m = __ballot(k0 == a);
+                if ((uint32_t)__builtin_popcountll(m) >= 16u) {
+                    key1 = a;
+                    have1 = true;
+                } else {
+                    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)k0, 32);
+                    m = __ballot(k0 == b);
+                    if ((uint32_t)__builtin_popcountll(m) >= 16u) {
+                        key1 = b;
+                        have1 = true;
+                    }
+                }
+                if (have1 && ~m != 0ull) {
+                    const uint32_t other = (uint32_t)__builtin_amdgcn_readlane((int)k0, (int)__builtin_ctzll(~m));
+                    if ((uint32_t)__builtin_popcountll(__ballot(k0 == other)) >= 8u) {
+                        key2 = other;
+                        have2 = true;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < VPT; u++) {
+            const uint32_t region0 = ((c + (uint32_t)u) * (uint32_t)(T * 4)) / region0_keys;   // a chunk lies in one region
+            const uint32_t k4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            if (have1) {
+                uint32_t n1 = 0, n2 = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const bool h1 = k4[q] == key1, h2 = have2 && k4[q] == key2;
+                    n1 += (uint32_t)__builtin_popcountll(__ballot(h1));
+                    n2 += (uint32_t)__builtin_popcountll(__ballot(h2));
+                    if (!(h1 || h2)) count_plain(k4[q], region0);
+                }
+                if (lane == 0) {
+                    if (n1) {
+                        atomicAdd(&s_a[slot_a(key1, region0)], n1);
+                        atomicAdd(&s_b[key1 >> kHybridBucketShift], n1);
+                    }
+                    if (n2) {
+                        atomicAdd(&s_a[slot_a(key2, region0)], n2);
+                        atomicAdd(&s_b[key2 >> kHybridBucketShift], n2);
+                    }
+                }
+                continue;
+            }
+            // sorted or constant input: the wave's 64 first keys share their bucket -> look at each of the four key slots
+            const uint32_t b0 = k4[0] >> kHybridBucketShift;
+            if (__ballot(b0 != (uint32_t)__builtin_amdgcn_readfirstlane(b0)) == 0ull) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t bq = k4[q] >> kHybridBucketShift, first = (uint32_t)__builtin_amdgcn_readfirstlane(bq);
+                    const uint32_t sa = slot_a(k4[q], region0), first_a = (uint32_t)__builtin_amdgcn_readfirstlane(sa);
+                    if (__ballot(bq != first || sa != first_a) == 0ull) {
+                        if (lane == 0) {
+                            atomicAdd(&s_b[first], 64u);
+                            atomicAdd(&s_a[first_a], 64u);
+                        }
+                    } else {
+                        count_plain(k4[q], region0);
+                    }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) count_plain(k4[q], region0);
+        }
+    };
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* __restrict__ k4p = reinterpret_cast<const u32x4*>(keys);
+    auto load_group = [&](uint32_t c, uint4 (&v)[VPT]) {
+#pragma unroll
+        for (int u = 0; u < VPT; u++) {
+            const u32x4 t = __builtin_nontemporal_load(k4p + (size_t)(c + u) * T + tid);
+            v[u] = make_uint4(t.x, t.y, t.z, t.w);
+        }
+    };
+    const uint32_t full_chunks = vec_chunks / VPT * VPT;
+    const uint32_t stride = gridDim.x * VPT;
+    uint32_t c = blockIdx.x * VPT;
+    if (c < full_chunks) {
+        uint4 buf_a[VPT], buf_b[VPT];
+        load_group(c, buf_a);
+        for (;;) {
+            const uint32_t c1 = c + stride;
+            const bool more1 = c1 < full_chunks;
+            load_group(more1 ? c1 : c, buf_b);
+            count_group(c, buf_a);
+            if (!more1) break;
+            const uint32_t c2 = c1 + stride;
+            const bool more2 = c2 < full_chunks;
+            load_group(more2 ? c2 : c1, buf_a);
+            count_group(c1, buf_b);
+            if (!more2) break;
+            c = c2;
+        }
+    }
+    // tail (and everything, for a base that is not 16-byte aligned: vec_chunks == 0): one key per thread per step
+    for (size_t i = (size_t)full_chunks * (T * 4) + (size_t)blockIdx.x * T + tid; i < n; i += (size_t)gridDim.x * T)
+        count_plain(keys[i], (uint32_t)(i / region0_keys));
+    __syncthreads();
+    for (uint32_t j = tid; j < FA; j += T) {   // global layout [digit][region], LDS layout [region][digit][copy]
+        const uint32_t d = j >> 3, x = j & 7u;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int q = 0; q < CA; q++) cnt += s_a[((x << 8) | d) * CA + q];
+        if (cnt) atomicAdd(&field_a[j], cnt);
+    }
+    for (uint32_t j = tid; j < NB; j += T) {
+        const uint32_t cnt = s_b[j];
+        if (cnt) atomicAdd(&bucket[j], cnt);
+    }
+}
+
+hipError_t launch_hybrid_histograms(const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field_a, uint32_t* bucket,
+                                    hipStream_t stream)
+{
+    constexpr int T = kHybridHistThreads;
+    constexpr size_t lds_bytes = (size_t)(2048 * kHybridCopiesA + kHybridBuckets) * sizeof(uint32_t);
+    static_assert(lds_bytes <= 160 * 1024, "one workgroup per CU");
+    if (region0_keys == 0 || region0_keys % (T * 4) != 0) return hipErrorInvalidValue;
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_histograms_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (attr != hipSuccess) return attr;
+    const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
+    const uint32_t vec_chunks = aligned ? n / (T * 4) : 0;
+    // one resident workgroup per CU, each flushing 34816 counters once: more workgroups would only flush more
+    uint32_t blocks = aligned ? (vec_chunks + kHybridVpt - 1) / kHybridVpt : (n + T * 16 - 1) / (T * 16);
+    if (blocks > 256) blocks = 256;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(hybrid_histograms_kernel, dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks);
+    return hipGetLastError();
+}
+
+// The planner: one workgroup.  From the bucket counts: the verdict (largest bucket <= kLocalSortCap and the counts sum to n),
+// the buckets' bases (exclusive scan, kHybridBuckets + 1 words), the second global pass's (digit, region) counts -- region =
+// top three bits of the first pass's digit, i.e. sixteen consecutive buckets per cell -- and the plan words the other kernels read.
+__global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __restrict__ bucket, uint32_t n, uint32_t* __restrict__ bases,
+                                                           uint32_t* __restrict__ field_b, uint32_t* __restrict__ words)
+{
+    constexpr uint32_t PER = kHybridBuckets / 1024;   // 32 consecutive buckets per thread = two (digit, region) cells
+    __shared__ uint32_t s_wave[16], s_max[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t cnt[PER];
+    const uint4* src = reinterpret_cast<const uint4*>(bucket + (size_t)tid * PER);
+#pragma unroll
+    for (int j = 0; j < (int)PER / 4; j++) {
+        const uint4 t = src[j];
+        cnt[4 * j] = t.x; cnt[4 * j + 1] = t.y; cnt[4 * j + 2] = t.z; cnt[4 * j + 3] = t.w;
+    }
+    uint32_t sum = 0, mx = 0, half0 = 0;
+#pragma unroll
+    for (int j = 0; j < (int)PER; j++) {
+        if (j == (int)PER / 2) half0 = sum;
+        sum += cnt[j];
+        mx = cnt[j] > mx ? cnt[j] : mx;
+    }
+    field_b[2 * tid] = half0;             // cell (digit, region) = buckets [32 t, 32 t + 16): the layout of a pass's count table
+    field_b[2 * tid + 1] = sum - half0;
+    uint32_t incl = wave_inclusive_scan(sum, lane);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t other = __shfl_xor(mx, off, kWave);
+        mx = other > mx ? other : mx;
+    }
+    if (lane == 63u) s_wave[wave] = incl;
+    if (lane == 0u) s_max[wave] = mx;
+    __syncthreads();
+    uint32_t carry = 0, total = 0, largest = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        carry += (uint32_t)w < wave ? s_wave[w] : 0u;
+        total += s_wave[w];
+        largest = s_max[w] > largest ? s_max[w] : largest;
+    }
+    uint32_t run = carry + incl - sum;
+#pragma unroll
+    for (int j = 0; j < (int)PER; j++) {
+        bases[(size_t)tid * PER + j] = run;
+        run += cnt[j];
+    }
+    if (tid == 0) {
+        bases[kHybridBuckets] = n;
+        const uint32_t ok = (largest <= (uint32_t)kLocalSortCap && total == n) ? 1u : 0u;
+        words[kHybridWordOk] = ok;            // the ordinary form's kernels return at once when this is set
+        words[kHybridWordSkipLocal] = ok ^ 1u;
+        words[kHybridWordPlanA] = ok ^ 1u;     // PassParams::plan of the first global pass: skip?, roles swapped?
+        words[kHybridWordPlanA + 1] = 0u;
+        words[kHybridWordPlanB] = ok ^ 1u;
+        words[kHybridWordPlanB + 1] = 1u;      // the second pass reads what the first one wrote
+        words[kHybridWordLargest] = largest;
+    }
+}
+
+hipError_t launch_hybrid_plan(const uint32_t* bucket, uint32_t n, uint32_t* bases, uint32_t* field_b, uint32_t* words, hipStream_t stream)
+{
+    hipLaunchKernelGGL(hybrid_plan_kernel, dim3(1), dim3(1024), 0, stream, bucket, n, bases, field_b, words);
+    return hipGetLastError();
+}
+
+}  // namespace lsd

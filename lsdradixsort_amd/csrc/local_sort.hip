@@ -1,0 +1,148 @@
+// local_sort.hip -- the last stage of the hybrid form: buckets that fit the LDS, one workgroup each.
+//
+// No counterpart in the reference (its every pass goes through global memory, LSDRadixSort.cu:839-910).  After the hybrid form's two
+// global passes on the key's two high bytes the array is sorted by its top 16 bits, i.e. cut into 2^15 buckets of equal top-15-bit
+// value whose sizes the upfront read has counted exactly (hybrid.hip).  A bucket of at most kLocalCap keys is then finished
+// where it lies: one 512-thread workgroup loads it, runs the remaining digit passes -- the same stable rank (one returning LDS add
+// per key against wave-private counters) and the same LDS reorder as a global pass, but from LDS to LDS -- and stores it back
+// in place.  8 B/key of HBM traffic for the low 17 bits instead of 16 B/key for two more global passes, and no chained scan:
+// buckets are independent.
+//
+// Per workgroup (T = 512 threads, up to K = 32 keys each, two workgroups per CU):
+//   load, wave-striped: wave w owns positions [w * rows * 64, (w + 1) * rows * 64) of the bucket, lane l's i-th register holds
+//                       position w * rows * 64 + i * 64 + l, rows = ceil(size / T); positions past the bucket hold 0xFFFFFFFF
+//                       (the highest digit in every pass and the highest positions: they stay at the end and are never stored)
+//   per digit pass    : zero the wave's counters | rank = returning add | barrier | one thread per digit: wave bases + exclusive
+//                       scan over digits | barrier | keys -> LDS at (base + rank) | barrier | read back in position order
+//   store             : from LDS, linear.
+// Counters are 16 bits wide, two to a word (a wave holds at most 2048 keys): 8 waves x 512 digits in 8 KiB, so that two
+// workgroups share a CU (72 KiB each) and one's loads and barriers hide under the other's LDS work.
+#include "lsd_device.hpp"
+#include "lsd_kernels.hpp"
+
+namespace lsd {
+
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+
+constexpr int kLocalThreads = 512;
+constexpr int kLocalK = 32;
+constexpr int kLocalWaves = kLocalThreads / kWave;
+constexpr int kLocalMaxBins = 512;
+static_assert(kLocalThreads * kLocalK == kLocalSortCap, "the capacity the planner checks buckets against");
+constexpr size_t kLocalLdsWords = (size_t)kLocalSortCap + kLocalWaves * (kLocalMaxBins / 2) + 64;
+
+__global__ void __launch_bounds__(kLocalThreads, 4) local_sort_kernel(const LocalSortParams p)
+{
+    constexpr int T = kLocalThreads, K = kLocalK, W = kLocalWaves, HW = kLocalMaxBins / 2;   // HW: counter words per wave
+    if (p.skip && *p.skip != 0u) return;   // uniform: the plan took the other form
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    lds_u32* const s_keys = (lds_u32*)smem;                               // [kLocalSortCap]
+    volatile lds_u32* const s_cnt = (volatile lds_u32*)(s_keys + kLocalSortCap);   // [W][HW] words = [W][512] 16-bit counters, then bases
+    volatile lds_u16* const s_cnt16 = (volatile lds_u16*)s_cnt;
+    lds_u32* const s_misc = (lds_u32*)(s_cnt + W * HW);
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t lo = p.bases[blockIdx.x], hi = p.bases[blockIdx.x + 1];
+    const uint32_t size = hi - lo;
+    if (size == 0u || hi < lo) return;
+    if (size > (uint32_t)kLocalSortCap) {   // the planner promised otherwise: say so, touch nothing
+        if (tid == 0 && p.fault) atomicOr(p.fault, 8u);
+        return;
+    }
+    uint32_t* const bucket = p.keys + lo;
+    const uint32_t rows = (size + (uint32_t)T - 1u) / (uint32_t)T;   // uniform, 1 .. K
+    const uint32_t wbase = wave * rows * 64u + lane;
+
+    uint32_t key[K], rank[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        if ((uint32_t)i < rows) {
+            const uint32_t pos = wbase + (uint32_t)i * 64u;
+            key[i] = pos < size ? bucket[pos] : 0xFFFFFFFFu;
+        }
+    }
+
+    auto digit_pass = [&](uint32_t shift, uint32_t width) {
+        const uint32_t bins = 1u << width, mask = bins - 1u;
+        // this wave's counters start at zero (its own words only: LDS operations of a wave are served in order, and nobody
+        // else reads them before the barrier below)
+#pragma unroll
+        for (int j = 0; j < HW / kWave; j++) s_cnt[wave * HW + j * kWave + lane] = 0;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            if ((uint32_t)i < rows) {
+                const uint32_t d = (key[i] >> shift) & mask;
+                const uint32_t sh = (d & 1u) * 16u;
+                const uint32_t old = __hip_atomic_fetch_add((lds_u32*)&s_cnt[wave * HW + (d >> 1)], 1u << sh, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_WAVEFRONT);
+                rank[i] = (old >> sh) & 0xFFFFu;
+            }
+        }
+        __syncthreads();
+        // one thread per digit: the waves' counts become their bases inside the digit's range, the digits' totals an exclusive scan
+        uint32_t total = 0;
+        uint32_t wave_excl[W];
+        if (tid < bins) {
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                wave_excl[w] = total;
+                total += s_cnt16[w * kLocalMaxBins + tid];
+            }
+        }
+        uint32_t incl = wave_inclusive_scan(tid < bins ? total : 0u, lane);
+        if (lane == 63u) s_misc[wave] = incl;
+        __syncthreads();
+        uint32_t part[W];
+#pragma unroll
+        for (int w = 0; w < W; w++) part[w] = s_misc[w];
+        uint32_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) carry += (uint32_t)w < wave ? part[w] : 0u;
+        const uint32_t local_off = incl + carry - total;
+        if (tid < bins) {
+#pragma unroll
+            for (int w = 0; w < W; w++) s_cnt16[w * kLocalMaxBins + tid] = (uint16_t)(local_off + wave_excl[w]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            if ((uint32_t)i < rows) {
+                const uint32_t d = (key[i] >> shift) & mask;
+                s_keys[(uint32_t)s_cnt16[wave * kLocalMaxBins + d] + rank[i]] = key[i];
+            }
+        }
+        __syncthreads();
+    };
+    auto read_back = [&]() {   // position order again; the next pass's first barrier keeps its LDS writes behind these reads
+#pragma unroll
+        for (int i = 0; i < K; i++)
+            if ((uint32_t)i < rows) key[i] = s_keys[wbase + (uint32_t)i * 64u];
+    };
+
+    digit_pass(p.shift[0], p.width[0]);
+    if (p.width[1]) {
+        read_back();
+        digit_pass(p.shift[1], p.width[1]);
+    }
+    if (p.width[2]) {
+        read_back();
+        digit_pass(p.shift[2], p.width[2]);
+    }
+    for (uint32_t q = tid; q < size; q += (uint32_t)T) bucket[q] = s_keys[q];
+}
+
+hipError_t launch_local_sort(const LocalSortParams& p, hipStream_t stream)
+{
+    if (p.num_buckets == 0) return hipSuccess;
+    if (!p.keys || !p.bases || p.width[0] == 0) return hipErrorInvalidValue;
+    for (int i = 0; i < 3; i++)
+        if (p.width[i] > 9 || (p.width[i] && p.shift[i] + p.width[i] > 32)) return hipErrorInvalidValue;
+    constexpr size_t lds_bytes = kLocalLdsWords * sizeof(uint32_t);
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(local_sort_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(local_sort_kernel, dim3(p.num_buckets), dim3(kLocalThreads), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace lsd

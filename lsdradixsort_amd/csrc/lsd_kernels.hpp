@@ -161,15 +161,17 @@ hipError_t launch_scan_digit_counts(int radix_bits, int groups, const uint32_t* 
 // `keys` may be the slice [first_key, first_key + n) of the array (first_key a multiple of 4096): counts accumulate.
 hipError_t launch_joint_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys,
                                    uint32_t* joint, hipStream_t stream, const KeyTransform& xform = KeyTransform{},
-                                   uint32_t first_key = 0);
+                                   uint32_t first_key = 0, const uint32_t* skip = nullptr);   // *skip != 0: the launch does nothing
 
 // Stage 2, onesweep: region tables of every pass from the joint counts (`regions` = 16 or 32) or
 // from plain digit histograms (`regions` = 1; passes may then be 1 for the multi-GPU partition).
 // counts: [passes][2^R][regions]; tables: [passes][region_table_words(R)].
 // `fault` (may be null): the workspace fault word, raised (bit 2) if a pass's counts do not sum to n.
+// `hybrid_ok` (may be null): *hybrid_ok != 0 = the hybrid form runs instead: the plan then says "skip, and leave the status rows
+// alone" (2) for every pass and nothing else is written.
 hipError_t launch_scan_regions(int radix_bits, int passes, int regions, const uint32_t* counts, uint32_t n,
                                uint32_t tile_keys, uint32_t region0_keys, uint32_t* tables, hipStream_t stream,
-                               uint32_t* plan = nullptr, uint32_t* fault = nullptr);
+                               uint32_t* plan = nullptr, uint32_t* fault = nullptr, const uint32_t* hybrid_ok = nullptr);
 // The pass plan stage 2 writes when asked to (PassParams::plan): 2 words per pass, then plan[2 * passes] != 0 if the sorted
 // keys ended up in the second buffer.  launch_finish_plan copies them (and the payloads) back in that case.
 constexpr int kPlanWords = 2 * 16 + 1;   // up to 16 passes (2-bit digits)
@@ -186,6 +188,37 @@ hipError_t launch_tile_histograms(int radix_bits, const TileShape& shape, const 
 size_t tile_offsets_scratch_words(size_t tiles, int radix_bits);
 hipError_t launch_tile_offsets(int radix_bits, const uint32_t* hist, uint32_t* local, uint32_t* global,
                                uint32_t tiles, uint32_t* scratch, hipStream_t stream);
+
+// ---- the hybrid form's local stage (local_sort.hip) -------------------------------------------------------------------
+// Buckets of at most kLocalSortCap keys -- bucket b = keys [bases[b], bases[b + 1]) of `keys` -- are sorted in place, one workgroup
+// each, by up to three digit passes (shift, width <= 9 bits; width 0 = no pass) run from LDS to LDS.  A bucket above the
+// capacity raises fault bit 3 and is left alone.  *skip != 0 (may be null): the launch does nothing.
+constexpr int kLocalSortCap = 16384;
+struct LocalSortParams {
+    uint32_t* keys;
+    const uint32_t* bases;
+    uint32_t num_buckets;
+    uint32_t shift[3], width[3];
+    const uint32_t* skip;
+    uint32_t* fault;
+};
+hipError_t launch_local_sort(const LocalSortParams& p, hipStream_t stream);
+
+// ---- the hybrid form's upfront read and planner (hybrid.hip) ------------------------------------------------------------
+constexpr int kHybridBucketShift = 17;                       // a bucket = the keys that agree on their top 15 bits
+constexpr int kHybridBuckets = 1 << (32 - kHybridBucketShift);
+// plan words (uint32, in the workspace's control block): written by the planner, read by every kernel of either form
+constexpr int kHybridWordOk = 0;          // 1: the hybrid form runs (the ordinary form's kernels return at once)
+constexpr int kHybridWordSkipLocal = 1;   // 1: the local stage returns at once
+constexpr int kHybridWordPlanA = 2;       // PassParams::plan of the first global pass (two words)
+constexpr int kHybridWordPlanB = 4;       // ... of the second
+constexpr int kHybridWordLargest = 6;     // the largest bucket (diagnostics)
+constexpr int kHybridWords = 8;
+// field_a[(digit of bits 16-23) * 8 + position region] and bucket[key >> 17] += counts (both zero on entry)
+hipError_t launch_hybrid_histograms(const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field_a, uint32_t* bucket,
+                                    hipStream_t stream);
+// verdict, bucket bases (kHybridBuckets + 1 words), the second pass's (digit, region) counts field_b[2048], plan words
+hipError_t launch_hybrid_plan(const uint32_t* bucket, uint32_t n, uint32_t* bases, uint32_t* field_b, uint32_t* words, hipStream_t stream);
 
 // counts64[b] = hist32[b], b < bins (multi-GPU bucket sizes as uint64).
 hipError_t launch_widen_counts(const uint32_t* hist32, uint64_t* counts64, int bins, hipStream_t stream);

@@ -39,7 +39,17 @@ thread_local hipError_t g_last_hip = hipSuccess;
 constexpr size_t kAlign = 256;
 constexpr size_t kControlBytes = 256;            // u32[64]: [0] fault word, [16 .. 16 + kPlanWords) the pass plan
 constexpr size_t kPlanOffsetWords = 16;
-static_assert(kPlanOffsetWords + lsd::kPlanWords <= kControlBytes / sizeof(uint32_t), "the pass plan lives in the control block");
+constexpr size_t kHybridOffsetWords = kPlanOffsetWords + lsd::kPlanWords + 1;   // the hybrid form's plan words (hybrid.hip)
+static_assert(kHybridOffsetWords + lsd::kHybridWords <= kControlBytes / sizeof(uint32_t), "the plans live in the control block");
+std::atomic<int> g_hybrid{[] {                                          // lsdsort_set_hybrid; LSDSORT_HYBRID=0 starts it off
+    const char* e = getenv("LSDSORT_HYBRID");
+    return (e && e[0] == '0') ? 0 : 1;
+}()};
+// The hybrid form is tried for keys-only 8-bit-digit sorts whose AVERAGE top-15-bit bucket leaves the local stage room: 4096 ..
+// 14648 keys per bucket (below, 32768 workgroups of almost nothing cost more than the two passes they replace; above, the largest
+// bucket of even uniform keys nears the 16384-key capacity).  Whether it RUNS is decided on the device from the exact bucket counts.
+constexpr size_t kHybridMinKeys = (size_t)1 << 27;
+constexpr size_t kHybridMaxKeys = (size_t)480 * 1000 * 1000;
 std::atomic<int> g_skip_dead_passes{[] {                                // lsdsort_set_pass_skipping; LSDSORT_PASS_SKIPPING=0 starts it off
     const char* e = getenv("LSDSORT_PASS_SKIPPING");
     return (e && e[0] == '0') ? 0 : 1;
@@ -123,6 +133,8 @@ struct Layout {
     size_t alt_keys = 0;
     size_t alt_vals = 0;
     size_t alt_more[2] = {0, 0};   // further payload arrays (records: lsdsort_multi_u32_device)
+    size_t hyb_counts = 0;         // hybrid form (8-bit digits): field A [256][8] | field B [256][8] | buckets [32768], zeroed
+    size_t hyb_bases = 0;          // [32769] bucket bases
     size_t total = 0;
     uint32_t tiles = 0;      // ceil(n / tile)
     uint32_t rows = 0;       // onesweep: status rows = grid size = tiles + one ragged tile per region
@@ -146,17 +158,26 @@ Layout make_layout(size_t n, int radix_bits, int payloads, int algorithm, const 
         L.regions = lsd::regions_for_radix(radix_bits);
         L.rows = L.tiles + (uint32_t)L.regions;          // one ragged last tile per region at most
         L.region0 = region0_keys(n, tile, L.regions);
+        const size_t hyb = radix_bits == 8 ? 2 : 0;   // the hybrid form's two global passes have ticket, count and table slots of their own
         L.tickets = off;
-        off = align_up(off + passes * lsd::kMaxRegions * sizeof(uint32_t));
+        off = align_up(off + (passes + hyb) * lsd::kMaxRegions * sizeof(uint32_t));
         L.counts = off;
         off = align_up(off + passes * bins * (size_t)L.regions * sizeof(uint32_t));
+        if (hyb) {
+            L.hyb_counts = off;
+            off = align_up(off + (2 * bins * (size_t)L.regions + lsd::kHybridBuckets) * sizeof(uint32_t));
+        }
         L.status = off;
         off = align_up(off + (size_t)L.rows * bins * sizeof(uint32_t));
         L.zero_bytes = off;
         L.status_odd = off;
         off = align_up(off + (size_t)L.rows * bins * sizeof(uint32_t));
         L.tables = off;
-        off = align_up(off + passes * lsd::region_table_words(radix_bits) * sizeof(uint32_t));
+        off = align_up(off + (passes + hyb) * lsd::region_table_words(radix_bits) * sizeof(uint32_t));
+        if (hyb) {
+            L.hyb_bases = off;
+            off = align_up(off + (size_t)(lsd::kHybridBuckets + 1) * sizeof(uint32_t));
+        }
     } else {
         L.zero_bytes = off;
         L.tile_hist = off;
@@ -384,13 +405,33 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     uint32_t* plan = nullptr;
     if (algorithm == LSDSORT_ALGO_ONESWEEP && !xf.on && 2 * passes + 1 <= lsd::kPlanWords && g_skip_dead_passes.load(std::memory_order_relaxed))
         plan = control + kPlanOffsetWords;
+    // The hybrid form (hybrid.hip): two global passes on the high bytes, then every top-15-bit bucket finished in LDS -- 28 B/key
+    // instead of 36.  Tried here for keys-only sorts of the sizes it pays for; the device decides from the exact bucket counts, and
+    // every kernel of the form that does NOT run returns at once (plan words in the control block).
+    uint32_t* hyb = nullptr;
+    if (plan && radix_bits == 8 && !pairs && !feed && rank_method == lsd::kRankLdsAdd && n >= kHybridMinKeys && n <= kHybridMaxKeys &&
+        shape->tile() == 32768 && g_hybrid.load(std::memory_order_relaxed))
+        hyb = control + kHybridOffsetWords;
+    if (timing) timing->hybrid = hyb ? -1 : 0;   // -1: tried; lsdsort_u32_device_timed reads the device's verdict back
     if (algorithm == LSDSORT_ALGO_ONESWEEP) {
         uint32_t* counts = reinterpret_cast<uint32_t*>(ws + L.counts);
         tables = reinterpret_cast<uint32_t*>(ws + L.tables);
+        if (hyb) {
+            uint32_t* field_a = reinterpret_cast<uint32_t*>(ws + L.hyb_counts);
+            uint32_t* field_b = field_a + 256 * L.regions;
+            uint32_t* bucket = field_b + 256 * L.regions;
+            LSD_HIP(lsd::launch_hybrid_histograms(d_keys, (uint32_t)n, L.region0, field_a, bucket, stream));
+            LSD_HIP(lsd::launch_hybrid_plan(bucket, (uint32_t)n, reinterpret_cast<uint32_t*>(ws + L.hyb_bases), field_b, hyb, stream));
+            // the two global passes' region tables: pass A's regions are by position (like any first pass), pass B's by the top
+            // bits of A's digit -- exactly what stage 2 builds for two consecutive passes
+            LSD_HIP(lsd::launch_scan_regions(radix_bits, 2, L.regions, field_a, (uint32_t)n, (uint32_t)shape->tile(), L.region0,
+                                             tables + (size_t)passes * table_words, stream, nullptr, control));
+        }
         // stage 1 over [first, first + len): the whole array at once, or chunk by chunk behind the host's copies
         auto histogram = [&](size_t first, size_t len) -> int {
             if (L.regions > 1)
-                LSD_HIP(lsd::launch_joint_histograms(radix_bits, d_keys + first, (uint32_t)len, L.region0, counts, stream, xf, (uint32_t)first));
+                LSD_HIP(lsd::launch_joint_histograms(radix_bits, d_keys + first, (uint32_t)len, L.region0, counts, stream, xf, (uint32_t)first,
+                                                     hyb ? hyb + lsd::kHybridWordOk : nullptr));
             else
                 LSD_HIP(lsd::launch_digit_histograms(radix_bits, passes, 0, d_keys + first, (uint32_t)len, counts, stream));
             return LSDSORT_OK;
@@ -427,8 +468,42 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
         }
 #endif
         LSD_HIP(lsd::launch_scan_regions(radix_bits, passes, L.regions, counts, (uint32_t)n, (uint32_t)shape->tile(),
-                                         L.region0, tables, stream, plan, control));
+                                         L.region0, tables, stream, plan, control, hyb ? hyb + lsd::kHybridWordOk : nullptr));
         if (ev) LSD_TRY(ev->mark());
+        if (hyb) {
+            // pass A: bits 16-23, caller's buffer -> alternate; pass B: bits 24-31, back; then the buckets in place
+            for (int g = 0; g < 2; g++) {
+                PassParams p{};
+                p.in = d_keys;
+                p.out = alt_keys;
+                p.n = (uint32_t)n;
+                p.shift = (uint32_t)(16 + 8 * g);
+                p.num_tiles = L.rows;
+                p.fault = control;
+                p.spin_limit = g_spin_limit.load(std::memory_order_relaxed);
+                p.regions = tables + (size_t)(passes + g) * table_words;
+                p.status = reinterpret_cast<uint32_t*>(ws + (g ? L.status_odd : L.status));
+                p.status_clear = g == 0 ? reinterpret_cast<uint32_t*>(ws + L.status_odd) : nullptr;
+                p.tickets = reinterpret_cast<uint32_t*>(ws + L.tickets) + (size_t)(passes + g) * lsd::kMaxRegions;
+                p.plan = hyb + (g ? lsd::kHybridWordPlanB : lsd::kHybridWordPlanA);
+                p.stats = g_stats.load(std::memory_order_relaxed);
+                if (ev) LSD_TRY(ev->arm_kernel_events());
+                const hipError_t launched = lsd::launch_rank_scatter(radix_bits, *shape, rank_method, true, p, stream);
+                StageEvents::disarm_kernel_events();
+                LSD_HIP(launched);
+            }
+            lsd::LocalSortParams lp{};
+            lp.keys = d_keys;
+            lp.bases = reinterpret_cast<const uint32_t*>(ws + L.hyb_bases);
+            lp.num_buckets = (uint32_t)lsd::kHybridBuckets;
+            lp.shift[0] = 0; lp.width[0] = 9;      // bits 0-8, then 9-16: the 17 bits below a bucket's own
+            lp.shift[1] = 9; lp.width[1] = 8;
+            lp.skip = hyb + lsd::kHybridWordSkipLocal;
+            lp.fault = control;
+            if (ev) LSD_TRY(ev->mark());
+            LSD_HIP(lsd::launch_local_sort(lp, stream));
+            if (ev) LSD_TRY(ev->mark());
+        }
     } else if (ev) {
         LSD_TRY(ev->mark());
         LSD_TRY(ev->mark());
@@ -699,6 +774,12 @@ int lsdsort_set_xcd_chunk(int chunk)
     return LSDSORT_OK;
 }
 
+int lsdsort_set_hybrid(int on)
+{
+    g_hybrid.store(on ? 1 : 0, std::memory_order_relaxed);
+    return LSDSORT_OK;
+}
+
 int lsdsort_set_pass_skipping(int on)
 {
     g_skip_dead_passes.store(on ? 1 : 0, std::memory_order_relaxed);
@@ -893,9 +974,22 @@ int lsdsort_u32_device_timed(uint32_t* d_keys, uint32_t* d_vals, void* d_workspa
             LSD_HIP(hipEventElapsedTime(&out->histogram_ms, ev.ev[1], ev.ev[2]));
             LSD_HIP(hipEventElapsedTime(&out->scan_ms, ev.ev[2], ev.ev[3]));
             if (algorithm == LSDSORT_ALGO_ONESWEEP) {
-                // marks: 3 = before the first pass, 4 = after the last; per pass: the kernel's own events
-                for (int p = 0; p < out->passes && p < LSDSORT_MAX_PASSES && 2 * p + 1 < ev.kernel_count; p++)
-                    LSD_HIP(hipEventElapsedTime(&out->scatter_ms[p], ev.kernel_ev[2 * p], ev.kernel_ev[2 * p + 1]));
+                // marks: 3 = before the first pass, the last = after the last; per pass: the kernel's own events.  Where the hybrid
+                // form was tried its two global passes come first (event pairs 0 and 1) and marks 4, 5 bracket the local stage.
+                int first_pair = 0;
+                if (out->hybrid == -1) {
+                    uint32_t ok = 0;
+                    LSD_HIP(hipMemcpy(&ok, static_cast<const uint32_t*>(d_workspace) + kHybridOffsetWords + lsd::kHybridWordOk, sizeof(ok),
+                                      hipMemcpyDeviceToHost));
+                    out->hybrid = ok ? 1 : 0;
+                    first_pair = ok ? 0 : 2;
+                    if (ok) {
+                        out->passes = 2;
+                        if (ev.count >= 6) LSD_HIP(hipEventElapsedTime(&out->local_ms, ev.ev[4], ev.ev[5]));
+                    }
+                }
+                for (int p = 0; p < out->passes && p < LSDSORT_MAX_PASSES && 2 * (p + first_pair) + 1 < ev.kernel_count; p++)
+                    LSD_HIP(hipEventElapsedTime(&out->scatter_ms[p], ev.kernel_ev[2 * (p + first_pair)], ev.kernel_ev[2 * (p + first_pair) + 1]));
             } else {
                 out->histogram_ms = 0.f;
                 out->scan_ms = 0.f;
@@ -992,6 +1086,30 @@ int lsdsort_rank_scatter_u32_device(const uint32_t* d_in, uint32_t* d_out, const
     p.global_off = d_global;
     LSD_HIP(lsd::launch_rank_scatter(radix_bits, *shape, resolve_rank_method(dev, radix_bits), false, p,
                                      static_cast<hipStream_t>(hip_stream)));
+    return LSDSORT_OK;
+}
+
+int lsdsort_local_sort_u32_device(uint32_t* d_keys, const uint32_t* d_bases, size_t num_buckets, int low_bits, void* hip_stream)
+{
+    if (low_bits < 1 || low_bits > 27 || num_buckets > 0xffffffffu) return LSDSORT_ERR_INVALID_ARG;
+    if (num_buckets == 0) return LSDSORT_OK;
+    if (!d_keys || !d_bases) return LSDSORT_ERR_INVALID_ARG;
+    int dev = 0;
+    LSD_TRY(check_device_ready(&dev));
+    if (!g_device[dev].lds_add_in_lane_order) return LSDSORT_ERR_UNSUPPORTED;   // the local stage ranks by returning LDS adds only
+    lsd::LocalSortParams p{};
+    p.keys = d_keys;
+    p.bases = d_bases;
+    p.num_buckets = (uint32_t)num_buckets;
+    const int passes = (low_bits + 8) / 9;                     // digits of at most nine bits, as even as they come
+    int shift = 0;
+    for (int i = 0; i < passes; i++) {
+        const int width = (low_bits - shift + (passes - i) - 1) / (passes - i);
+        p.shift[i] = (uint32_t)shift;
+        p.width[i] = (uint32_t)width;
+        shift += width;
+    }
+    LSD_HIP(lsd::launch_local_sort(p, static_cast<hipStream_t>(hip_stream)));
     return LSDSORT_OK;
 }
 

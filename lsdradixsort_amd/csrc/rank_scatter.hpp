@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         __syncthreads();
         region = __builtin_amdgcn_readfirstlane(s_misc[28]);
         if (region == 0xFFFFFFFFu) {         // uniform: the grid is an upper bound on the tile count
-            clear_next();
+            if (plan_skip != 2u) clear_next();   // 2: the other form of the sort runs (hybrid.hip); this pass owns nothing
             return;
         }
         chain_pos = __builtin_amdgcn_readfirstlane(s_misc[29]);

@@ -1,0 +1,108 @@
+"""The hybrid form of large keys-only 8-bit sorts (hybrid.hip, local_sort.hip): two global passes on the high bytes, then every
+top-15-bit bucket finished in LDS.  No reference counterpart (every reference pass goes through global memory,
+LSDRadixSort.cu:844-905); the RESULT has one: the sorted array (.cu:1018, .cu:120).  Checked bit-exact against torch.sort of
+the same device array, with the form switched on and off, on keys for which the device takes it and on keys for which it
+must refuse it -- and the local stage on its own against numpy.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _u64(t):
+    import torch
+
+    return t.to(torch.int64) & 0xFFFFFFFF
+
+
+def _i32(x):
+    import torch
+
+    return ((x + (1 << 31)) % (1 << 32) - (1 << 31)).to(torch.int32)
+
+
+def test_local_stage_alone(gpu):
+    """lsdsort_local_sort_u32_device: buckets of every shape a workgroup meets -- empty, one key, around a row of 512, around
+    the 16384-key capacity (the larger one must be left untouched) -- sorted in place by their low 9 / 17 / 24 / 27 bits."""
+    import torch
+
+    rng = np.random.default_rng(11)
+    sizes = [0, 1, 2, 63, 64, 65, 511, 512, 513, 1000, 4096, 8191, 8192, 16383, 16384, 16385, 0, 7, 12345]
+    bases = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    n = int(bases[-1])
+    for low_bits in (9, 17, 24, 27, 1):
+        keys = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+        if low_bits == 24:
+            keys[: n // 2] &= np.uint32(0xFF0000FF)          # few distinct low values: heavy digits in every local pass
+        d = gpu.to_device(keys)
+        db = gpu.to_device(bases)
+        st = gpu.lib().lsdsort_local_sort_u32_device(d.data_ptr(), db.data_ptr(), len(sizes), low_bits, torch.cuda.current_stream().cuda_stream)
+        assert st == 0
+        got = gpu.to_host(d)
+        mask = np.uint32((1 << low_bits) - 1)
+        for b, size in enumerate(sizes):
+            lo, hi = int(bases[b]), int(bases[b + 1])
+            part = keys[lo:hi]
+            if size > 16384:
+                assert np.array_equal(got[lo:hi], part), "a bucket above the capacity was touched"
+                continue
+            order = np.argsort(part & mask, kind="stable")
+            assert np.array_equal(got[lo:hi], part[order]), (low_bits, b, size)
+
+
+@pytest.mark.parametrize("log2n,extra", [(27, 0), (27, 12345), (28, 777)])
+def test_hybrid_equals_torch_sort_and_the_four_pass_form(gpu, log2n, extra):
+    import torch
+
+    n = (1 << log2n) + extra
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4000 + log2n + extra)
+    base = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda", generator=gen)
+    ws = gpu.alloc_workspace(n, 8)
+    shapes = {
+        "uniform": lambda: base.clone(),
+        "sorted": lambda: _i32(torch.sort(_u64(base)).values),
+        "low_bits_dead": lambda: _i32(_u64(base) & 0xFFFFFE00),                       # the local stage's first digit constant
+        "half_zero": lambda: _i32(torch.where(((_u64(base) >> 13) & 1) != 0, _u64(base), torch.zeros_like(_u64(base)))),   # bucket 0 too large
+        "small_range": lambda: _i32(_u64(base) & 0x000FFFFF),                         # one bucket holds everything
+        "one_bucket_just_too_large": lambda: _i32(torch.cat([_u64(base[: n - 16385]), (_u64(base[:16385]) & 0x1FFFF) | (5 << 17)])),
+    }
+    taken = {}
+    for name, make in shapes.items():
+        keys = make()
+        expect = torch.sort(_u64(keys)).values
+        d = keys.clone()
+        tm = gpu.GPULSDRadixSortTimed(d, 8, workspace=ws)
+        taken[name] = tm["hybrid"]
+        assert torch.equal(_u64(d), expect), (name, "hybrid on", tm["hybrid"])
+        assert gpu.lib().lsdsort_check_device(ws.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0, name
+        gpu.set_hybrid(False)
+        try:
+            d2 = keys.clone()
+            tm2 = gpu.GPULSDRadixSortTimed(d2, 8, workspace=ws)
+            assert tm2["hybrid"] == 0
+            assert torch.equal(d2, d), (name, "the two forms differ")
+        finally:
+            gpu.set_hybrid(True)
+        del keys, expect, d, d2
+    assert taken["uniform"] == 1 and taken["sorted"] == 1 and taken["low_bits_dead"] == 1, taken
+    assert taken["half_zero"] == 0 and taken["small_range"] == 0 and taken["one_bucket_just_too_large"] == 0, taken
+
+
+def test_hybrid_is_not_tried_outside_its_range(gpu):
+    """Below 2^27 keys, with payloads, at 4-bit digits and for typed keys the four-pass form runs (lsdsort_timing.hybrid = 0)."""
+    import torch
+
+    n = (1 << 26) + 5
+    d = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda")
+    expect = torch.sort(_u64(d)).values
+    tm = gpu.GPULSDRadixSortTimed(d, 8)
+    assert tm["hybrid"] == 0 and torch.equal(_u64(d), expect)
+    n = (1 << 27) + 3
+    d = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda")
+    v = torch.arange(n, dtype=torch.int32, device="cuda")
+    tm = gpu.GPULSDRadixSortTimed(d.clone(), 8, d_vals=v)
+    assert tm["hybrid"] == 0
+    tm = gpu.GPULSDRadixSortTimed(d.clone(), 4)
+    assert tm["hybrid"] == 0
