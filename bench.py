@@ -76,6 +76,11 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample-log2", type=int, default=28,
                     help="keys of the workload the CPU baseline sorts (default: all 2^28 of config 3, about 16 s of std::sort on one core)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configs reported under 'extra'")
+    ap.add_argument("--no-hybrid", action="store_true",
+                    help="keys-only 8-bit sorts: always the four global passes (lsdsort_set_hybrid(0)); default: the library decides "
+                         "on the device whether two global passes + the LDS-resident local stage can run")
+    ap.add_argument("--sub-buckets", type=int, default=1, choices=[1, 2, 4],
+                    help="N > 1: sub-bucket pipelining of the sharded step (lsdsort_comm_set_sub_buckets)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic in this very run (N = 1 only; "
                          "the committed profiles/pmc_summary.json figure is reported instead, labelled as such)")
@@ -118,6 +123,8 @@ def spawn_ranks(n_ranks, argv, device_count=None, child_cmd=None, timeout=None, 
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     cmd = list(child_cmd) if child_cmd is not None else [sys.executable, os.path.abspath(__file__)] + list(argv)
+    import threading
+
     procs = []
     for r in range(n_ranks):
         env = dict(os.environ)
@@ -125,6 +132,11 @@ def spawn_ranks(n_ranks, argv, device_count=None, child_cmd=None, timeout=None, 
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # rank 0's stdout is drained WHILE the ranks run: read only at the end, a rank 0 that writes more than the pipe holds
+    # (64 KiB: NCCL_DEBUG=INFO does) would block in write() and this loop would poll for ever
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     deadline = None if timeout is None else time.time() + timeout
     rc = 0
     pending = set(range(n_ranks))
@@ -148,7 +160,8 @@ def spawn_ranks(n_ranks, argv, device_count=None, child_cmd=None, timeout=None, 
             procs[r].wait(timeout=10)
         except subprocess.TimeoutExpired:
             procs[r].kill()
-    text = procs[0].stdout.read() if procs[0].stdout else ""
+    reader.join(timeout=10)
+    text = "".join(chunks)
     if rc == 0:
         out.write(text)
         out.flush()
@@ -158,11 +171,12 @@ def spawn_ranks(n_ranks, argv, device_count=None, child_cmd=None, timeout=None, 
 
 
 def live_pmc_traffic(radix_bits, pairs, log2n, timeout=240):
-    """HBM bytes per launch of the rank-and-scatter kernel measured NOW, as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE and
+    """HBM bytes per launch of the sort's kernels measured NOW, as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE and
     WRITE_SIZE from SEPARATE `rocprofv3 --pmc` passes (counters only, no tracing), each over a child process that runs the same sort
     on the same input (tools/prof_target.py; the program after `--` is python3 itself); both counters are in KiB; FETCH_SIZE reports
     half of a coalesced streaming read and is doubled, the doubling calibrated on the upfront histogram kernel's known 4*n read.
-    Returns None (with a reason on stderr) if rocprofv3 is missing or a pass fails: the caller then falls back to the committed figure."""
+    Launches that returned at once (the kernels of the form of the sort that did NOT run) are left out.  Returns a dict by kernel
+    class -- "rank_scatter", "stage1", "local" -- or None (with a reason on stderr) if rocprofv3 is missing or a pass fails."""
     import csv
     import glob
     import shutil
@@ -177,6 +191,7 @@ def live_pmc_traffic(radix_bits, pairs, log2n, timeout=240):
     target = [sys.executable, os.path.join(ROOT, "tools", "prof_target.py"), "--log2-keys", str(log2n), "--radix-bits", str(radix_bits),
               "--steps", "2"] + (["--pairs"] if pairs else [])
     env = dict(os.environ, TMPDIR="/tmp")
+    classes = {"rank_scatter_kernel": "rank_scatter", "histograms_kernel": "stage1", "local_sort_kernel": "local"}
     got = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -187,29 +202,35 @@ def live_pmc_traffic(radix_bits, pairs, log2n, timeout=240):
             if p.returncode != 0 or not files:
                 print(f"bench.py: rocprofv3 --pmc {counter} failed (rc {p.returncode}); roofline.traffic falls back", file=sys.stderr)
                 return None
-            scatter, hist, dur = [], [], []
+            per = {}
             for row in csv.DictReader(open(files[0])):
                 if row["Counter_Name"] != counter:
                     continue
-                if "rank_scatter_kernel" in row["Kernel_Name"]:
-                    scatter.append(float(row["Counter_Value"]))
-                    dur.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-                elif "histograms_kernel" in row["Kernel_Name"]:
-                    hist.append(float(row["Counter_Value"]))
-            if not scatter:
-                return None
-            got[counter] = (sum(scatter) / len(scatter) * 1024.0, (sum(hist) / len(hist) * 1024.0) if hist else None,
-                            sum(dur) / len(dur) / 1e3, len(scatter))
+                dur_us = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
+                for needle, cls in classes.items():
+                    if needle in row["Kernel_Name"] and dur_us > 60.0:      # a launch that really ran (n >= 2^24)
+                        per.setdefault(cls, []).append((float(row["Counter_Value"]) * 1024.0, dur_us))
+            got[counter] = per
     except Exception as e:      # a profiler problem must not take the benchmark down
         print(f"bench.py: live PMC pass failed ({e}); roofline.traffic falls back", file=sys.stderr)
         return None
     finally:
         shutil.rmtree(out, ignore_errors=True)
-    fetch, hist_fetch, fetch_us, launches = got["FETCH_SIZE"]
-    write, _, write_us, _ = got["WRITE_SIZE"]
-    return {"bytes": int(2.0 * fetch + write), "fetch_bytes_corrected": int(2.0 * fetch), "write_bytes": int(write),
-            "calibration_ratio": round(2.0 * hist_fetch / (4.0 * n), 4) if hist_fetch else None, "launches": launches,
-            "kernel_us_under_profiler": round((fetch_us + write_us) / 2.0, 1)}
+    result = {}
+    for cls in ("rank_scatter", "stage1", "local"):
+        f, w = got["FETCH_SIZE"].get(cls), got["WRITE_SIZE"].get(cls)
+        if not f or not w:
+            continue
+        fetch = sum(x for x, _ in f) / len(f)
+        write = sum(x for x, _ in w) / len(w)
+        us = (sum(t for _, t in f) / len(f) + sum(t for _, t in w) / len(w)) / 2.0
+        result[cls] = {"bytes": int(2.0 * fetch + write), "fetch_bytes_corrected": int(2.0 * fetch), "write_bytes": int(write),
+                       "launches": len(f), "kernel_us_under_profiler": round(us, 1)}
+    if "rank_scatter" not in result:
+        return None
+    if "stage1" in result:
+        result["calibration_ratio"] = round(result["stage1"]["fetch_bytes_corrected"] / (4.0 * n), 4)
+    return result
 
 
 def timed_steps(run_step, pools, steps, warmup, sync):
@@ -262,7 +283,7 @@ def main(argv=None):
     # multi-process GPU work on this image needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return spawn_ranks(args.gpus, argv)          # plain `python bench.py --gpus N`: this process only launches
+        return spawn_ranks(args.gpus, argv, timeout=3000.0)   # plain `python bench.py --gpus N`: this process only launches
     import numpy as np
     import torch
 
@@ -300,6 +321,8 @@ def main(argv=None):
         lsd.set_tile_config(r, args.tile_config)
     if args.rank_method >= 0:
         lsd.set_rank_method(args.rank_method)
+    if args.no_hybrid:
+        lsd.set_hybrid(False)
     log2_keys, scaling = keys_per_gpu_log2(args, world)
     n = 1 << log2_keys
     passes = 32 // r
@@ -331,7 +354,7 @@ def main(argv=None):
         exchange_path = "c++"
         backend, why = None, ""
         try:
-            backend = ShardedSorter(r, partition=args.partition)
+            backend = ShardedSorter(r, partition=args.partition, sub_buckets=args.sub_buckets)
             probe = backend.sort(master[: min(n, 1 << 16)].clone())
             torch.cuda.synchronize()
             if backend.check_fault() != 0:
@@ -406,9 +429,10 @@ def main(argv=None):
         return None, None
 
     def measure_roofline(keys_t, vals_t, rb, pairs, nn, wsx, reps=5):
-        """The dominant kernel's own begin/end events (hipExtLaunchKernelGGL on the launch stream) over `reps` sorts."""
-        scat, hist, scan, clear, totals = [], [], [], [], []
-        tile = None
+        """The dominant kernel's own begin/end events (hipExtLaunchKernelGGL on the launch stream) over `reps` sorts.  Where the
+        hybrid form runs (lsdsort_timing.hybrid) the global passes are its two, and the local stage is timed by marker events."""
+        scat, hist, scan, clear, totals, local = [], [], [], [], [], []
+        tile, hybrid, global_passes = None, 0, 32 // rb
         for _ in range(reps):
             # an untimed sort is queued right in front of the timed one (no synchronise between them), so that the timed
             # kernels run as they do inside the timed region -- back to back behind another sort, clocks and caches in
@@ -418,11 +442,14 @@ def main(argv=None):
             kk, vv = keys_t(), (vals_t() if pairs else None)
             tm = lsd.GPULSDRadixSortTimed(kk, rb, d_vals=vv, algorithm=algo, workspace=wsx)
             tile = tm["tile_keys"]
+            hybrid = tm["hybrid"]
+            global_passes = tm["passes"]
             scat += tm["scatter_ms"]
             hist.append(tm["histogram_ms"])
             scan.append(tm["scan_ms"])
             clear.append(tm["clear_ms"])
             totals.append(tm["total_ms"])
+            local.append(tm["local_ms"])
         per_key = 16 if pairs else 8               # one read + one write of the key (and payload) per pass
         scat_ms = float(np.mean(scat))
         achieved = per_key * nn / (scat_ms * 1e-3) / 1e9
@@ -430,9 +457,11 @@ def main(argv=None):
         roof = {"bound": "hbm", "kernel": "rank_scatter_kernel", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": source, "algorithmic_bytes_per_launch": per_key * nn,
-                "launch_ms": round(scat_ms, 4)}
+                "launch_ms": round(scat_ms, 4), "launches_per_sort": global_passes}
         stages = {"clear": round(float(np.mean(clear)), 4), "histogram": round(float(np.mean(hist)), 4),
                   "scan": round(float(np.mean(scan)), 4), "scatter_per_pass": round(scat_ms, 4),
+                  "global_passes": global_passes, "hybrid_form": bool(hybrid),
+                  "local_stage": round(float(np.mean(local)), 4) if hybrid else None,
                   "total_event": round(float(np.mean(totals)), 4)}
         return roof, stages, tile
 
@@ -446,16 +475,45 @@ def main(argv=None):
         sort_bytes = (4 + 16 * passes) * n if args.pairs else 4 * (2 * passes + 1) * n
         stage_ms["sort_algorithmic_gbs"] = round(sort_bytes / (ms_per_step * 1e-3) / 1e9, 1) if not distributed else None
         stage_ms["sort_roofline_frac"] = round(sort_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if not distributed else None
+        if stage_ms["hybrid_form"] and not distributed:
+            # what the sort that ran really moves: one counting read, two global passes, one local stage = 4 + 3 x 8 B/key
+            moved = 28 * n
+            stage_ms["sort_moved_bytes_per_key"] = 28
+            stage_ms["sort_moved_gbs"] = round(moved / (ms_per_step * 1e-3) / 1e9, 1)
+            stage_ms["sort_moved_frac_of_peak"] = round(moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            stage_ms["accounting"] = ("sort_roofline_frac prices the sort at SURVEY 8d's algorithmic 36 B/key (a four-pass 8-bit LSD sort); the hybrid "
+                                      "form moves 28 B/key (sort_moved_*): the last two digits are sorted inside the CUs' LDS")
         roofline["rank_method"] = lsd.rank_method(r)
         if not distributed and not args.no_live_traffic and args.algorithm == "onesweep" and args.tile_config < 0:
             live = live_pmc_traffic(r, args.pairs, log2_keys)
             if live is not None:
-                roofline["traffic"] = live["bytes"]
+                rs = live["rank_scatter"]
+                roofline["traffic"] = rs["bytes"]
                 roofline["traffic_source"] = ("measured in this run: two separate rocprofv3 --pmc passes (FETCH_SIZE x 2, WRITE_SIZE; KiB) over "
-                                              f"child processes running the same sort on the same input (tools/prof_target.py), {live['launches']} launches, "
-                                              f"kernel {live['kernel_us_under_profiler']} us under the profiler; FETCH_SIZE x 2 on the histogram kernel's "
-                                              f"known 4n read: ratio {live['calibration_ratio']}")
-                roofline["traffic_over_algorithmic"] = round(live["bytes"] / roofline["algorithmic_bytes_per_launch"], 4)
+                                              f"child processes running the same sort on the same input (tools/prof_target.py), {rs['launches']} launches, "
+                                              f"kernel {rs['kernel_us_under_profiler']} us under the profiler; FETCH_SIZE x 2 on the upfront read's "
+                                              f"known 4n bytes: ratio {live.get('calibration_ratio')}")
+                roofline["traffic_over_algorithmic"] = round(rs["bytes"] / roofline["algorithmic_bytes_per_launch"], 4)
+                # the other two kernels of the sort, priced the same way (VERDICT r2 task 3: a roofline object for stage 1).  Their
+                # durations come from the profiler's own dispatch timestamps in these passes (no launch-stream events inside the
+                # library for them), so they read a little long against an unprofiled run.
+                per_item = 8 if args.pairs else 4
+                if "stage1" in live:
+                    st = live["stage1"]
+                    ach = per_item * n / (st["kernel_us_under_profiler"] * 1e-6) / 1e9
+                    roofline["stage1"] = {"bound": "hbm", "kernel": "hybrid_histograms_kernel" if stage_ms["hybrid_form"] else "joint_histograms_kernel",
+                                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                          "traffic": st["bytes"], "algorithmic_bytes_per_launch": per_item * n,
+                                          "launch_ms": round(st["kernel_us_under_profiler"] / 1e3, 4), "launches_per_sort": 1,
+                                          "timing": "rocprofv3 dispatch timestamps of the PMC passes"}
+                if "local" in live:
+                    lc = live["local"]
+                    ach = 8 * n / (lc["kernel_us_under_profiler"] * 1e-6) / 1e9
+                    roofline["local_stage"] = {"bound": "hbm", "kernel": "local_sort_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": lc["bytes"],
+                                               "algorithmic_bytes_per_launch": 8 * n, "launch_ms": round(lc["kernel_us_under_profiler"] / 1e3, 4),
+                                               "launches_per_sort": 1, "timing": "rocprofv3 dispatch timestamps of the PMC passes",
+                                               "note": "two digit passes from LDS to LDS per bucket: bound by LDS work, not by HBM"}
 
     # ---- secondary configs on the same box (N=1 only): configs[1] (r=4) and configs[4] (pairs), stage rows ----
     extra = {}
@@ -495,10 +553,33 @@ def main(argv=None):
         extra["r4_256M_keys_mkeys_s"] = extra["config2_r4_256M_keys"]["value"]
         extra["pairs_r8_128M_pairs_mpairs_s"] = extra["config5_pairs_r8_128M_pairs"]["value"]
 
+        # The four-pass form (every digit through global memory, the reference's structure) on the same input, when the headline
+        # ran the hybrid form: lsdsort_set_hybrid(0).
+        if stage_ms["hybrid_form"]:
+            lsd.set_hybrid(False)
+            try:
+                copies = [master.clone() for _ in range(9)]
+                lsd.GPULSDRadixSort(copies[0], r, algorithm=algo, workspace=ws)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for kk in copies[1:]:
+                    lsd.GPULSDRadixSort(kk, r, algorithm=algo, workspace=ws)
+                torch.cuda.synchronize()
+                ms4 = (time.perf_counter() - t0) / 8 * 1e3
+                roof4, stages4, _ = measure_roofline(lambda: pool.fresh()[0], lambda: None, r, False, n, ws, reps=3)
+                del copies
+            finally:
+                lsd.set_hybrid(True)
+            extra["four_pass_form"] = {"value": round(n / (ms4 * 1e-3) / 1e6, 1), "unit": "Mkeys/s", "ms_per_step": round(ms4, 4),
+                                       "sort_roofline_frac": round(36 * n / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "roofline": roof4, "stages_ms": stages4,
+                                       "note": "lsdsort_set_hybrid(0): four global passes, 36 B/key moved (the structure of GPULSDRadixSort, .cu:844-905)"}
+
         # What the default rank form (one returning LDS add per key, probed on the device) buys over the
         # architecture-guaranteed peer-mask form: the same sort with lsdsort_set_rank_method(0) and (2).
         def method_ms(m, steps=4):
             lsd.set_rank_method(m)
+            lsd.set_hybrid(False)           # like with like: the hybrid form needs rank form 2, so both run the four-pass form
             copies = [master.clone() for _ in range(steps + 1)]
             lsd.GPULSDRadixSort(copies[0], r, algorithm=algo, workspace=ws)
             torch.cuda.synchronize()
@@ -509,8 +590,9 @@ def main(argv=None):
             return (time.perf_counter() - t0) / steps * 1e3
         ab0, ab2 = method_ms(0), method_ms(2)
         lsd.set_rank_method(args.rank_method if args.rank_method >= 0 else -1)
+        lsd.set_hybrid(not args.no_hybrid)
         extra["rank_method_ab"] = {"method_0_peer_mask_ms": round(ab0, 4), "method_2_lds_add_ms": round(ab2, 4),
-                                   "in_use": lsd.rank_method(r),
+                                   "in_use": lsd.rank_method(r), "form": "four global passes (hybrid form off for both)",
                                    "opt_out": "lsdsort_set_rank_method(0) (include/lsdsort.h); method 2 is only used when the device probe passes"}
 
         # Key distributions the reference never tests: made on the device from the workload's keys, sorted
@@ -621,15 +703,18 @@ def main(argv=None):
                         f"local {r}-bit LSD sort ({passes} passes) per step"
                         + (" [BASELINE configs[3]]" if n * world == 1 << 30 and world == 8 else ""))
         else:
+            form = (", hybrid form (digits 2 and 3 by two global passes, digits 0 and 1 inside each CU's LDS; decided on the device)"
+                    if stage_ms and stage_ms.get("hybrid_form") else f", {passes} global passes")
             workload = (f"2^{log2_keys} uniform uint32 {'key+payload pairs' if args.pairs else 'keys'} per GPU "
-                        f"(mt19937 seed=rank), {r}-bit radix, {passes} passes, {args.algorithm}, device-resident")
+                        f"(mt19937 seed=rank), {r}-bit radix{form}, {args.algorithm}, device-resident")
         line = {
             "metric": "Mkeys/s sorting uniform uint32, 1 GiB, 1/2/4/8 MI355X; % HBM roofline",
             "value": round(mkeys, 1), "unit": "Mkeys/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": workload, "keys_per_gpu": n, "total_keys": n * world, "radix_bits": r,
-                       "algorithm": args.algorithm, "pairs": bool(args.pairs), "tile_keys": sort_tile_keys},
+                       "algorithm": args.algorithm, "pairs": bool(args.pairs), "tile_keys": sort_tile_keys,
+                       "hybrid_form": bool(stage_ms and stage_ms.get("hybrid_form"))},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "stages_ms": stage_ms, "extra": extra,
         }
         print(json.dumps(line), flush=True)

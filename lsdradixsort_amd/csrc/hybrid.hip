@@ -27,9 +27,9 @@ constexpr int kHybridVpt = 4;              // 16-byte vectors per thread per gro
 
 // Upfront read of the hybrid form.  fieldA[(digit of bits 16-23) * 8 + position region] and bucket[key >> 17] (global, zero on
 // entry) receive the counts.  Grid-stride over chunks of 4096 keys, two register buffers, non-temporal loads (as stage 1 of the
-// ordinary form, aux_kernels.hip).  Heavy values are handled as there, in the two shapes that matter for THESE fields: keys equal
-// to a sticky candidate value (zeros, a default value) are counted by ballot, and a vector whose 256 keys agree on their bucket
-// (sorted or constant input) adds once per wave.
+// ordinary form, aux_kernels.hip).  Heavy values are handled as there: keys equal to a sticky candidate value (zeros, a default
+// value) are counted by ballot for both fields at once, and per field the holders of the first lane's counter are counted by
+// ballot when sixteen lanes or more share it (sorted or constant input, dead digits, small ranges).
 __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                                uint32_t region0_keys, uint32_t* __restrict__ field_a,
                                                                                uint32_t* __restrict__ bucket, uint32_t vec_chunks)
@@ -104,26 +104,42 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
                 }
                 continue;
             }
-            // sorted or constant input: the wave's 64 first keys share their bucket -> look at each of the four key slots
-            const uint32_t b0 = k4[0] >> kHybridBucketShift;
-            if (__ballot(b0 != (uint32_t)__builtin_amdgcn_readfirstlane(b0)) == 0ull) {
+            // Heavy FIELD values (sorted or constant input, dead digits, small key ranges: many lanes on one counter, which
+            // the LDS serves a lane per clock): per field, if sixteen lanes or more of the vector's first keys share the first
+            // lane's counter, its holders among all four keys are counted by ballot and added once; everybody else adds for
+            // itself.  Uniform keys pay the two looks (a few scalar instructions per vector).
+            {
+                const uint32_t a0 = slot_a(k4[0], region0), a_first = (uint32_t)__builtin_amdgcn_readfirstlane(a0);
+                if ((uint32_t)__builtin_popcountll(__ballot(a0 == a_first)) >= 16u) {
+                    uint32_t held = 0;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t bq = k4[q] >> kHybridBucketShift, first = (uint32_t)__builtin_amdgcn_readfirstlane(bq);
-                    const uint32_t sa = slot_a(k4[q], region0), first_a = (uint32_t)__builtin_amdgcn_readfirstlane(sa);
-                    if (__ballot(bq != first || sa != first_a) == 0ull) {
-                        if (lane == 0) {
-                            atomicAdd(&s_b[first], 64u);
-                            atomicAdd(&s_a[first_a], 64u);
-                        }
-                    } else {
-                        count_plain(k4[q], region0);
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t sa = slot_a(k4[q], region0);
+                        const bool h = sa == a_first;
+                        held += (uint32_t)__builtin_popcountll(__ballot(h));
+                        if (!h) atomicAdd(&s_a[sa + copy], 1u);
                     }
-                }
-                continue;
-            }
+                    if (lane == 0) atomicAdd(&s_a[a_first], held);
+                } else {
 #pragma unroll
-            for (int q = 0; q < 4; q++) count_plain(k4[q], region0);
+                    for (int q = 0; q < 4; q++) atomicAdd(&s_a[slot_a(k4[q], region0) + copy], 1u);
+                }
+                const uint32_t b0 = k4[0] >> kHybridBucketShift, b_first = (uint32_t)__builtin_amdgcn_readfirstlane(b0);
+                if ((uint32_t)__builtin_popcountll(__ballot(b0 == b_first)) >= 16u) {
+                    uint32_t held = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t sb = k4[q] >> kHybridBucketShift;
+                        const bool h = sb == b_first;
+                        held += (uint32_t)__builtin_popcountll(__ballot(h));
+                        if (!h) atomicAdd(&s_b[sb], 1u);
+                    }
+                    if (lane == 0) atomicAdd(&s_b[b_first], held);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) atomicAdd(&s_b[k4[q] >> kHybridBucketShift], 1u);
+                }
+            }
         }
     };
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -196,11 +212,14 @@ hipError_t launch_hybrid_histograms(const uint32_t* keys, uint32_t n, uint32_t r
 // the buckets' bases (exclusive scan, kHybridBuckets + 1 words), the second global pass's (digit, region) counts -- region =
 // top three bits of the first pass's digit, i.e. sixteen consecutive buckets per cell -- and the plan words the other kernels read.
 __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __restrict__ bucket, uint32_t n, uint32_t* __restrict__ bases,
-                                                           uint32_t* __restrict__ field_b, uint32_t* __restrict__ words)
+                                                           uint32_t* __restrict__ field_b, uint32_t* __restrict__ words,
+                                                           uint32_t* __restrict__ large_list)
 {
     constexpr uint32_t PER = kHybridBuckets / 1024;   // 32 consecutive buckets per thread = two (digit, region) cells
-    __shared__ uint32_t s_wave[16], s_max[16];
+    __shared__ uint32_t s_wave[16], s_max[16], s_large;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) s_large = 0;
+    __syncthreads();
     uint32_t cnt[PER];
     const uint4* src = reinterpret_cast<const uint4*>(bucket + (size_t)tid * PER);
 #pragma unroll
@@ -214,6 +233,9 @@ __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __res
         if (j == (int)PER / 2) half0 = sum;
         sum += cnt[j];
         mx = cnt[j] > mx ? cnt[j] : mx;
+        // the local stage's small variant (three workgroups per CU) takes buckets up to kLocalSortCapSmall keys; the others
+        // go on a list that a second, small launch walks with the large variant
+        if (cnt[j] > (uint32_t)kLocalSortCapSmall) large_list[atomicAdd(&s_large, 1u)] = tid * PER + (uint32_t)j;
     }
     field_b[2 * tid] = half0;             // cell (digit, region) = buckets [32 t, 32 t + 16): the layout of a pass's count table
     field_b[2 * tid + 1] = sum - half0;
@@ -244,6 +266,7 @@ __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __res
         const uint32_t ok = (largest <= (uint32_t)kLocalSortCap && total == n) ? 1u : 0u;
         words[kHybridWordOk] = ok;            // the ordinary form's kernels return at once when this is set
         words[kHybridWordSkipLocal] = ok ^ 1u;
+        words[kHybridWordLargeCount] = s_large;
         words[kHybridWordPlanA] = ok ^ 1u;     // PassParams::plan of the first global pass: skip?, roles swapped?
         words[kHybridWordPlanA + 1] = 0u;
         words[kHybridWordPlanB] = ok ^ 1u;
@@ -252,9 +275,10 @@ __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __res
     }
 }
 
-hipError_t launch_hybrid_plan(const uint32_t* bucket, uint32_t n, uint32_t* bases, uint32_t* field_b, uint32_t* words, hipStream_t stream)
+hipError_t launch_hybrid_plan(const uint32_t* bucket, uint32_t n, uint32_t* bases, uint32_t* field_b, uint32_t* words, uint32_t* large_list,
+                              hipStream_t stream)
 {
-    hipLaunchKernelGGL(hybrid_plan_kernel, dim3(1), dim3(1024), 0, stream, bucket, n, bases, field_b, words);
+    hipLaunchKernelGGL(hybrid_plan_kernel, dim3(1), dim3(1024), 0, stream, bucket, n, bases, field_b, words, large_list);
     return hipGetLastError();
 }
 

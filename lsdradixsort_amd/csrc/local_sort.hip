@@ -25,28 +25,36 @@ namespace lsd {
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
 constexpr int kLocalThreads = 512;
-constexpr int kLocalK = 32;
 constexpr int kLocalWaves = kLocalThreads / kWave;
 constexpr int kLocalMaxBins = 512;
-static_assert(kLocalThreads * kLocalK == kLocalSortCap, "the capacity the planner checks buckets against");
-constexpr size_t kLocalLdsWords = (size_t)kLocalSortCap + kLocalWaves * (kLocalMaxBins / 2) + 64;
+static_assert(kLocalThreads * 32 == kLocalSortCap, "the capacity the planner checks buckets against");
+static_assert(kLocalThreads * 20 == kLocalSortCapSmall, "the capacity of the three-per-CU variant");
+template <int K>
+constexpr size_t local_lds_words() { return (size_t)kLocalThreads * K + kLocalWaves * (kLocalMaxBins / 2) + 64; }
 
-__global__ void __launch_bounds__(kLocalThreads, 4) local_sort_kernel(const LocalSortParams p)
+// K = 32: buckets of up to 16384 keys, 72 KiB of LDS, two workgroups per CU.  K = 20: up to 10240 keys, 48 KiB, THREE per CU
+// (and at most 80 registers): the stage is bound by LDS work that one workgroup's barriers and loads leave idle, so the third
+// resident workgroup is worth about a fifth of its time.  The planner knows the largest bucket and picks (LocalSortParams::skip
+// of the other launch); uniform keys at 2^28 have buckets of 8192 +- 300.
+template <int K>
+__device__ __forceinline__ void sort_bucket(const LocalSortParams& p, const uint32_t b)
 {
-    constexpr int T = kLocalThreads, K = kLocalK, W = kLocalWaves, HW = kLocalMaxBins / 2;   // HW: counter words per wave
-    if (p.skip && *p.skip != 0u) return;   // uniform: the plan took the other form
+    constexpr int T = kLocalThreads, W = kLocalWaves, HW = kLocalMaxBins / 2;   // HW: counter words per wave
+    constexpr int CAP = T * K;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    lds_u32* const s_keys = (lds_u32*)smem;                               // [kLocalSortCap]
-    volatile lds_u32* const s_cnt = (volatile lds_u32*)(s_keys + kLocalSortCap);   // [W][HW] words = [W][512] 16-bit counters, then bases
+    lds_u32* const s_keys = (lds_u32*)smem;                               // [CAP]
+    volatile lds_u32* const s_cnt = (volatile lds_u32*)(s_keys + CAP);   // [W][HW] words = [W][512] 16-bit counters, then bases
     volatile lds_u16* const s_cnt16 = (volatile lds_u16*)s_cnt;
     lds_u32* const s_misc = (lds_u32*)(s_cnt + W * HW);
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t lo = p.bases[blockIdx.x], hi = p.bases[blockIdx.x + 1];
+    const uint32_t lo = p.bases[b], hi = p.bases[b + 1];
     const uint32_t size = hi - lo;
     if (size == 0u || hi < lo) return;
-    if (size > (uint32_t)kLocalSortCap) {   // the planner promised otherwise: say so, touch nothing
-        if (tid == 0 && p.fault) atomicOr(p.fault, 8u);
+    if (size > (uint32_t)CAP) {
+        // the small variant leaves larger buckets to the listed launch; above the large capacity the planner promised
+        // otherwise: say so, touch nothing
+        if (!p.larger_elsewhere && tid == 0 && p.fault) atomicOr(p.fault, 8u);
         return;
     }
     uint32_t* const bucket = p.keys + lo;
@@ -131,17 +139,52 @@ __global__ void __launch_bounds__(kLocalThreads, 4) local_sort_kernel(const Loca
     for (uint32_t q = tid; q < size; q += (uint32_t)T) bucket[q] = s_keys[q];
 }
 
+// one bucket per workgroup
+template <int K>
+__global__ void __launch_bounds__(kLocalThreads, (K <= 20 ? 6 : 4)) local_sort_kernel(const LocalSortParams p)
+{
+    if (p.skip && *p.skip != 0u) return;   // uniform: the plan took the other form
+    sort_bucket<K>(p, blockIdx.x);
+}
+
+// The buckets of the planner's list (those above the small variant's capacity), dealt over a small grid: uniform keys leave
+// the list empty, and a launch of 32768 workgroups that each find nothing to do costs 17 us.
+template <int K>
+__global__ void __launch_bounds__(kLocalThreads, (K <= 20 ? 6 : 4)) local_sort_list_kernel(const LocalSortParams p)
+{
+    if (p.skip && *p.skip != 0u) return;
+    const uint32_t listed = *p.list_count;
+    for (uint32_t item = blockIdx.x; item < listed; item += gridDim.x) {
+        sort_bucket<K>(p, p.list[item]);
+        __syncthreads();   // the next bucket reuses the LDS
+    }
+}
+
 hipError_t launch_local_sort(const LocalSortParams& p, hipStream_t stream)
 {
     if (p.num_buckets == 0) return hipSuccess;
     if (!p.keys || !p.bases || p.width[0] == 0) return hipErrorInvalidValue;
     for (int i = 0; i < 3; i++)
         if (p.width[i] > 9 || (p.width[i] && p.shift[i] + p.width[i] > 32)) return hipErrorInvalidValue;
-    constexpr size_t lds_bytes = kLocalLdsWords * sizeof(uint32_t);
-    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(local_sort_kernel),
+    if ((p.list == nullptr) != (p.list_count == nullptr)) return hipErrorInvalidValue;
+    if (p.small_variant) {
+        if (p.list) return hipErrorInvalidValue;   // the list is the large variant's
+        constexpr size_t lds_bytes = local_lds_words<20>() * sizeof(uint32_t);
+        hipLaunchKernelGGL(local_sort_kernel<20>, dim3(p.num_buckets), dim3(kLocalThreads), lds_bytes, stream, p);
+        return hipGetLastError();
+    }
+    constexpr size_t lds_bytes = local_lds_words<32>() * sizeof(uint32_t);
+    if (p.list) {
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(local_sort_list_kernel<32>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (attr != hipSuccess) return attr;
+        hipLaunchKernelGGL(local_sort_list_kernel<32>, dim3(512), dim3(kLocalThreads), lds_bytes, stream, p);   // two workgroups per CU walk the list
+        return hipGetLastError();
+    }
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(local_sort_kernel<32>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(local_sort_kernel, dim3(p.num_buckets), dim3(kLocalThreads), lds_bytes, stream, p);
+    hipLaunchKernelGGL(local_sort_kernel<32>, dim3(p.num_buckets), dim3(kLocalThreads), lds_bytes, stream, p);
     return hipGetLastError();
 }
 

@@ -100,6 +100,10 @@ struct PassParams {
     // passes before this one really ran, so the keys are in `out` and go to `in` (the roles swap).  Written by stage 2
     // (scan_regions_kernel) from the digit counts; with it every pass is launched with the SAME in / out.
     const uint32_t* plan;
+    // plan[0] is looked at FIRST, and a pass it marks 2 ("the other form of the sort runs") returns before anything else: set for
+    // the four-pass form's launches of a sort that tried the hybrid form, which otherwise cost 16 us each to say no (8200
+    // workgroups that set up their LDS, take the barrier and leave).  The wait costs a pass that does run about 1 %.
+    uint32_t plan_first;
     uint32_t n;
     uint32_t shift;            // bit_group * radix_bits
     uint32_t num_tiles;        // grid size: chained = upper bound on the regions' tile counts
@@ -194,6 +198,7 @@ hipError_t launch_tile_offsets(int radix_bits, const uint32_t* hist, uint32_t* l
 // each, by up to three digit passes (shift, width <= 9 bits; width 0 = no pass) run from LDS to LDS.  A bucket above the
 // capacity raises fault bit 3 and is left alone.  *skip != 0 (may be null): the launch does nothing.
 constexpr int kLocalSortCap = 16384;
+constexpr int kLocalSortCapSmall = 10240;   // the three-workgroups-per-CU variant (small_variant)
 struct LocalSortParams {
     uint32_t* keys;
     const uint32_t* bases;
@@ -201,6 +206,10 @@ struct LocalSortParams {
     uint32_t shift[3], width[3];
     const uint32_t* skip;
     uint32_t* fault;
+    uint32_t small_variant;   // 1: buckets of up to kLocalSortCapSmall keys, three workgroups per CU
+    uint32_t larger_elsewhere;   // 1: a bucket above this launch's capacity is another launch's (no fault)
+    const uint32_t* list;        // null: bucket = workgroup index.  Else the buckets to sort, *list_count of them, walked by a
+    const uint32_t* list_count;  // grid of 512 workgroups
 };
 hipError_t launch_local_sort(const LocalSortParams& p, hipStream_t stream);
 
@@ -209,7 +218,8 @@ constexpr int kHybridBucketShift = 17;                       // a bucket = the k
 constexpr int kHybridBuckets = 1 << (32 - kHybridBucketShift);
 // plan words (uint32, in the workspace's control block): written by the planner, read by every kernel of either form
 constexpr int kHybridWordOk = 0;          // 1: the hybrid form runs (the ordinary form's kernels return at once)
-constexpr int kHybridWordSkipLocal = 1;   // 1: the local stage returns at once
+constexpr int kHybridWordSkipLocal = 1;   // 1: the local stage returns at once (both launches)
+constexpr int kHybridWordLargeCount = 7;  // buckets above the small variant's capacity: the entries of the planner's list
 constexpr int kHybridWordPlanA = 2;       // PassParams::plan of the first global pass (two words)
 constexpr int kHybridWordPlanB = 4;       // ... of the second
 constexpr int kHybridWordLargest = 6;     // the largest bucket (diagnostics)
@@ -218,7 +228,9 @@ constexpr int kHybridWords = 8;
 hipError_t launch_hybrid_histograms(const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field_a, uint32_t* bucket,
                                     hipStream_t stream);
 // verdict, bucket bases (kHybridBuckets + 1 words), the second pass's (digit, region) counts field_b[2048], plan words
-hipError_t launch_hybrid_plan(const uint32_t* bucket, uint32_t n, uint32_t* bases, uint32_t* field_b, uint32_t* words, hipStream_t stream);
+// ... and large_list[0 .. words[kHybridWordLargeCount]): the buckets of more than kLocalSortCapSmall keys (kHybridBuckets words)
+hipError_t launch_hybrid_plan(const uint32_t* bucket, uint32_t n, uint32_t* bases, uint32_t* field_b, uint32_t* words, uint32_t* large_list,
+                              hipStream_t stream);
 
 // counts64[b] = hist32[b], b < bins (multi-GPU bucket sizes as uint64).
 hipError_t launch_widen_counts(const uint32_t* hist32, uint64_t* counts64, int bins, hipStream_t stream);

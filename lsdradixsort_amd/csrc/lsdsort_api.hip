@@ -176,7 +176,7 @@ Layout make_layout(size_t n, int radix_bits, int payloads, int algorithm, const 
         off = align_up(off + (passes + hyb) * lsd::region_table_words(radix_bits) * sizeof(uint32_t));
         if (hyb) {
             L.hyb_bases = off;
-            off = align_up(off + (size_t)(lsd::kHybridBuckets + 1) * sizeof(uint32_t));
+            off = align_up(off + (size_t)(2 * lsd::kHybridBuckets + 1) * sizeof(uint32_t));   // bases, then the list of large buckets
         }
     } else {
         L.zero_bytes = off;
@@ -421,7 +421,8 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             uint32_t* field_b = field_a + 256 * L.regions;
             uint32_t* bucket = field_b + 256 * L.regions;
             LSD_HIP(lsd::launch_hybrid_histograms(d_keys, (uint32_t)n, L.region0, field_a, bucket, stream));
-            LSD_HIP(lsd::launch_hybrid_plan(bucket, (uint32_t)n, reinterpret_cast<uint32_t*>(ws + L.hyb_bases), field_b, hyb, stream));
+            uint32_t* bases = reinterpret_cast<uint32_t*>(ws + L.hyb_bases);
+            LSD_HIP(lsd::launch_hybrid_plan(bucket, (uint32_t)n, bases, field_b, hyb, bases + lsd::kHybridBuckets + 1, stream));
             // the two global passes' region tables: pass A's regions are by position (like any first pass), pass B's by the top
             // bits of A's digit -- exactly what stage 2 builds for two consecutive passes
             LSD_HIP(lsd::launch_scan_regions(radix_bits, 2, L.regions, field_a, (uint32_t)n, (uint32_t)shape->tile(), L.region0,
@@ -501,6 +502,13 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             lp.skip = hyb + lsd::kHybridWordSkipLocal;
             lp.fault = control;
             if (ev) LSD_TRY(ev->mark());
+            lp.small_variant = 1;     // buckets of up to 10240 keys (all of them on uniform keys of these sizes): three workgroups per CU
+            lp.larger_elsewhere = 1;
+            LSD_HIP(lsd::launch_local_sort(lp, stream));
+            lp.small_variant = 0;     // the planner's list of larger ones (up to 16384 keys): two per CU, a grid of 512 walks the list
+            lp.larger_elsewhere = 0;
+            lp.list = lp.bases + lsd::kHybridBuckets + 1;
+            lp.list_count = hyb + lsd::kHybridWordLargeCount;
             LSD_HIP(lsd::launch_local_sort(lp, stream));
             if (ev) LSD_TRY(ev->mark());
         }
@@ -554,6 +562,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
                 p.vals_in = d_vals;
                 p.vals_out = alt_vals;
                 p.plan = plan + 2 * pass;
+                p.plan_first = hyb ? 1u : 0u;   // a sort that tried the hybrid form: these passes leave at once if it runs
             }
             if (xf.on && pass == 0) p.xin = xf;
             if (xf.on && pass + 1 == passes) p.xout = xf;

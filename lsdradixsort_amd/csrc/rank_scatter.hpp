@@ -130,6 +130,7 @@ constexpr int rank_scatter_lds_words()
 template <int R, int T, int K, int CAP, int RANK, bool PAIRS, bool CHAINED, bool XF = false>
 __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_kernel(const PassParams p)
 {
+    if (CHAINED && p.plan_first && p.plan[0] == 2u) return;   // uniform (PassParams::plan_first)
 #ifdef LSD_PHASE_STATS
     unsigned long long stamp__ = __builtin_amdgcn_s_memrealtime();
     uint32_t stat_row__ = 0;   // status row of the tile being stamped
@@ -473,26 +474,18 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
             }
             // ... then the holders are ranked from the running counts: vector and scalar ALU only
             uint32_t c1 = 0, c2 = 0;
-            if (h2 != kNoDigit) {   // uniform
+            // (ONE loop for one or two candidates: h2 == kNoDigit matches no key.  A second, single-candidate copy of this
+            // unrolled loop saved the second ballot's six instructions per row on such waves, and cost every wave -- the
+            // plain path included -- 18 registers and a scratch slot: measured round 3, 110 -> 128 VGPRs + 8 B of scratch.)
 #pragma unroll
-                for (int i = 0; i < K; i++) {
-                    const uint32_t d = digit_of(key[i]);
-                    const bool in1 = d == h1, in2 = d == h2;
-                    const uint64_t m1 = __ballot(in1), m2 = __ballot(in2);
-                    const uint32_t r1 = mbcnt_add(m1, c1), r2 = mbcnt_add(m2, c2);
-                    rank[i] = in1 ? r1 : (in2 ? r2 : rank[i]);
-                    c1 = popc64_add(m1, c1);
-                    c2 = popc64_add(m2, c2);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < K; i++) {
-                    const bool in1 = digit_of(key[i]) == h1;
-                    const uint64_t m1 = __ballot(in1);
-                    const uint32_t r1 = mbcnt_add(m1, c1);
-                    rank[i] = in1 ? r1 : rank[i];
-                    c1 = popc64_add(m1, c1);
-                }
+            for (int i = 0; i < K; i++) {
+                const uint32_t d = digit_of(key[i]);
+                const bool in1 = d == h1, in2 = d == h2;
+                const uint64_t m1 = __ballot(in1), m2 = __ballot(in2);
+                const uint32_t r1 = mbcnt_add(m1, c1), r2 = mbcnt_add(m2, c2);
+                rank[i] = in1 ? r1 : (in2 ? r2 : rank[i]);
+                c1 = popc64_add(m1, c1);
+                c2 = popc64_add(m2, c2);
             }
             if (lane == 0) {
                 s_cnt[wave * H + h1] = c1;

@@ -67,7 +67,12 @@ def test_hybrid_equals_torch_sort_and_the_four_pass_form(gpu, log2n, extra):
         "half_zero": lambda: _i32(torch.where(((_u64(base) >> 13) & 1) != 0, _u64(base), torch.zeros_like(_u64(base)))),   # bucket 0 too large
         "small_range": lambda: _i32(_u64(base) & 0x000FFFFF),                         # one bucket holds everything
         "one_bucket_just_too_large": lambda: _i32(torch.cat([_u64(base[: n - 16385]), (_u64(base[:16385]) & 0x1FFFF) | (5 << 17)])),
+        # fifty buckets between the two capacities of the local stage (10240 < size <= 16384): the planner's list, walked by
+        # the large variant, while the small variant takes the other 32718
+        "fifty_buckets_above_the_small_capacity": lambda: _i32(torch.cat([
+            _u64(base[: n - 50 * hot]), (_u64(base[: 50 * hot]) & 0x1FFFF) | ((torch.arange(50 * hot, device="cuda") // hot * 601 + 77) << 17)])),
     }
+    hot = 16000 - (n >> 15) - 700          # a hot bucket: its share of the uniform keys plus this many, under 16384 in all
     taken = {}
     for name, make in shapes.items():
         keys = make()
@@ -87,6 +92,7 @@ def test_hybrid_equals_torch_sort_and_the_four_pass_form(gpu, log2n, extra):
             gpu.set_hybrid(True)
         del keys, expect, d, d2
     assert taken["uniform"] == 1 and taken["sorted"] == 1 and taken["low_bits_dead"] == 1, taken
+    assert taken["fifty_buckets_above_the_small_capacity"] == (1 if hot > 10240 - (n >> 15) else taken["fifty_buckets_above_the_small_capacity"]), taken
     assert taken["half_zero"] == 0 and taken["small_range"] == 0 and taken["one_bucket_just_too_large"] == 0, taken
 
 
