@@ -214,11 +214,11 @@ LSDSORT_API int lsdsort_rank_scatter_u32_device(const uint32_t* d_in, uint32_t* 
 
 /* The hybrid form's local stage on its own (lsdradixsort_amd/csrc/local_sort.hip): bucket b = d_keys[d_bases[b] .. d_bases[b + 1])
  * (num_buckets + 1 ascending device words) is sorted IN PLACE by its keys' low `low_bits` bits (1..27; stable LSD passes of at
- * most nine bits each, run from LDS to LDS by one workgroup per bucket).  Buckets of more than 16384 keys are left as they are
- * (inside a whole sort the planner has ruled them out).  Needs the returning-LDS-add rank form (LSDSORT_ERR_UNSUPPORTED where the
- * device probe failed). */
-LSDSORT_API int lsdsort_local_sort_u32_device(uint32_t* d_keys, const uint32_t* d_bases, size_t num_buckets, int low_bits,
-                                              void* hip_stream);
+ * most nine bits each, run from LDS to LDS by one workgroup per bucket); d_vals (may be NULL) holds a payload word per key that
+ * is permuted with it.  Buckets of more than 16384 keys are left as they are (inside a whole sort the planner has ruled them
+ * out).  Needs the returning-LDS-add rank form (LSDSORT_ERR_UNSUPPORTED where the device probe failed). */
+LSDSORT_API int lsdsort_local_sort_u32_device(uint32_t* d_keys, uint32_t* d_vals, const uint32_t* d_bases, size_t num_buckets,
+                                              int low_bits, void* hip_stream);
 
 /* One read of all keys -> all 32/radix_bits digit histograms, d_hist[g][d] (uint32). */
 LSDSORT_API int lsdsort_digit_histograms_u32_device(const uint32_t* d_keys, size_t n, int radix_bits,
@@ -379,10 +379,10 @@ LSDSORT_API int lsdsort_set_xcd_chunk(int chunk);
  * sorts and 1-bit digits always run every pass.  0 switches it off (every pass runs, as the reference's do). */
 LSDSORT_API int lsdsort_set_pass_skipping(int on);
 /* The hybrid form (lsdradixsort_amd/csrc/hybrid.hip, local_sort.hip; no reference counterpart -- its every pass goes through
- * global memory, .cu:844-905).  Keys-only sorts with 8-bit digits of 2^27 .. 4.8e8 keys: the two HIGH digits are sorted first
+ * global memory, .cu:844-905).  Sorts of keys or key/value pairs with 8-bit digits of 2^27 .. 4.8e8 items: the two HIGH digits are sorted first
  * by two ordinary global passes (LSD order: bits 16-23, then 24-31), which leaves the array sorted by its top 16 bits; every
  * bucket of equal top-15-bit value (2^15 of them) is then finished inside one CU's LDS (bits 0-8, then 9-16) and stored once:
- * 4 + 8 + 8 + 8 = 28 bytes per key of memory traffic instead of 4 + 4 x 8 = 36.  Valid only if every bucket fits the local stage
+ * 4 + 8 + 8 + 8 = 28 bytes per key of memory traffic instead of 4 + 4 x 8 = 36 (pairs: 52 instead of 68).  Valid only if every bucket fits the local stage
  * (16384 keys), which depends on the keys: the upfront read counts the buckets exactly and the DEVICE decides before a key is
  * moved; otherwise the ordinary four global passes run (after their own upfront read: such keys pay about 10 % for the
  * attempt).  Same result either way.  On by default; 0 = always the four global passes, as the reference's structure. */

@@ -84,7 +84,7 @@ SIGNATURES = {
     "lsdsort_tile_offsets_u32_device": (c_int, [c_u32p, c_u32p, c_u32p, c_size, c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "lsdsort_rank_scatter_u32_device": (c_int, [c_u32p, c_u32p, c_u32p, c_u32p, c_u32p, c_size, c_int, c_int,
                                                 ctypes.c_void_p]),
-    "lsdsort_local_sort_u32_device": (c_int, [c_u32p, c_u32p, c_size, c_int, ctypes.c_void_p]),
+    "lsdsort_local_sort_u32_device": (c_int, [c_u32p, c_u32p, c_u32p, c_size, c_int, ctypes.c_void_p]),
     "lsdsort_digit_histograms_u32_device": (c_int, [c_u32p, c_size, c_int, c_u32p, ctypes.c_void_p]),
     "lsdsort_msb_partition_workspace_bytes": (c_size, [c_size, c_int]),
     "lsdsort_msb_partition_u32_device": (c_int, [c_u32p, c_u32p, c_size, c_int, ctypes.c_void_p, ctypes.c_void_p,

@@ -30,10 +30,39 @@ constexpr int kHybridVpt = 4;              // 16-byte vectors per thread per gro
 // ordinary form, aux_kernels.hip).  Heavy values are handled as there: keys equal to a sticky candidate value (zeros, a default
 // value) are counted by ballot for both fields at once, and per field the holders of the first lane's counter are counted by
 // ballot when sixteen lanes or more share it (sorted or constant input, dead digits, small ranges).
+// The sample: 65536 keys at a regular stride, 1024 per workgroup over 64 workgroups, each workgroup counting ITS samples by bucket
+// in LDS (one workgroup doing all of them waits 0.12 ms for its own 65536 cache lines; global counters melt on constant keys:
+// 65536 returning atomics on one word took 0.6 ms).  A bucket's share of a workgroup's 1024 samples is 1/32 of a key: eight in one
+// bucket -- 0.8 % of all keys, two hundred times a bucket's share -- raise the flag.
+__global__ void __launch_bounds__(1024) hybrid_sample_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ hopeless)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];   // [kHybridBuckets]
+    constexpr uint32_t kSamples = 65536;
+    const unsigned long long step = n / kSamples;   // n >= 2^27: at least 2048
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k = keys[(size_t)((unsigned long long)(blockIdx.x * 1024u + tid) * step)];
+    for (uint32_t j = tid; j < (uint32_t)kHybridBuckets; j += 1024) s_cnt[j] = 0;
+    __syncthreads();
+    if (atomicAdd(&s_cnt[k >> kHybridBucketShift], 1u) + 1u >= 8u) *hopeless = 1u;
+}
+
+hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, uint32_t* hopeless, hipStream_t stream)
+{
+    if (n < 65536u * 64u) return hipErrorInvalidValue;
+    constexpr size_t lds_bytes = (size_t)kHybridBuckets * sizeof(uint32_t);
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_sample_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(hybrid_sample_kernel, dim3(64), dim3(1024), lds_bytes, stream, keys, n, hopeless);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                                uint32_t region0_keys, uint32_t* __restrict__ field_a,
-                                                                               uint32_t* __restrict__ bucket, uint32_t vec_chunks)
+                                                                               uint32_t* __restrict__ bucket, uint32_t vec_chunks,
+                                                                               const uint32_t* __restrict__ skip)
 {
+    if (skip && *skip != 0u) return;   // uniform: the sample has ruled the hybrid form out (the planner then sees no counts: not ok)
     constexpr int T = kHybridHistThreads, CA = kHybridCopiesA, VPT = kHybridVpt;
     constexpr uint32_t FA = 2048, NB = kHybridBuckets;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
@@ -189,7 +218,7 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
 }
 
 hipError_t launch_hybrid_histograms(const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field_a, uint32_t* bucket,
-                                    hipStream_t stream)
+                                    const uint32_t* skip, hipStream_t stream)
 {
     constexpr int T = kHybridHistThreads;
     constexpr size_t lds_bytes = (size_t)(2048 * kHybridCopiesA + kHybridBuckets) * sizeof(uint32_t);
@@ -204,7 +233,7 @@ hipError_t launch_hybrid_histograms(const uint32_t* keys, uint32_t n, uint32_t r
     uint32_t blocks = aligned ? (vec_chunks + kHybridVpt - 1) / kHybridVpt : (n + T * 16 - 1) / (T * 16);
     if (blocks > 256) blocks = 256;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(hybrid_histograms_kernel, dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks);
+    hipLaunchKernelGGL(hybrid_histograms_kernel, dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks, skip);
     return hipGetLastError();
 }
 
@@ -213,7 +242,7 @@ hipError_t launch_hybrid_histograms(const uint32_t* keys, uint32_t n, uint32_t r
 // top three bits of the first pass's digit, i.e. sixteen consecutive buckets per cell -- and the plan words the other kernels read.
 __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __restrict__ bucket, uint32_t n, uint32_t* __restrict__ bases,
                                                            uint32_t* __restrict__ field_b, uint32_t* __restrict__ words,
-                                                           uint32_t* __restrict__ large_list)
+                                                           uint32_t* __restrict__ large_list, uint32_t small_cap)
 {
     constexpr uint32_t PER = kHybridBuckets / 1024;   // 32 consecutive buckets per thread = two (digit, region) cells
     __shared__ uint32_t s_wave[16], s_max[16], s_large;
@@ -235,7 +264,7 @@ __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __res
         mx = cnt[j] > mx ? cnt[j] : mx;
         // the local stage's small variant (three workgroups per CU) takes buckets up to kLocalSortCapSmall keys; the others
         // go on a list that a second, small launch walks with the large variant
-        if (cnt[j] > (uint32_t)kLocalSortCapSmall) large_list[atomicAdd(&s_large, 1u)] = tid * PER + (uint32_t)j;
+        if (cnt[j] > small_cap) large_list[atomicAdd(&s_large, 1u)] = tid * PER + (uint32_t)j;
     }
     field_b[2 * tid] = half0;             // cell (digit, region) = buckets [32 t, 32 t + 16): the layout of a pass's count table
     field_b[2 * tid + 1] = sum - half0;
@@ -276,9 +305,9 @@ __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __res
 }
 
 hipError_t launch_hybrid_plan(const uint32_t* bucket, uint32_t n, uint32_t* bases, uint32_t* field_b, uint32_t* words, uint32_t* large_list,
-                              hipStream_t stream)
+                              uint32_t small_cap, hipStream_t stream)
 {
-    hipLaunchKernelGGL(hybrid_plan_kernel, dim3(1), dim3(1024), 0, stream, bucket, n, bases, field_b, words, large_list);
+    hipLaunchKernelGGL(hybrid_plan_kernel, dim3(1), dim3(1024), 0, stream, bucket, n, bases, field_b, words, large_list, small_cap);
     return hipGetLastError();
 }
 

@@ -28,7 +28,7 @@ constexpr int kLocalThreads = 512;
 constexpr int kLocalWaves = kLocalThreads / kWave;
 constexpr int kLocalMaxBins = 512;
 static_assert(kLocalThreads * 32 == kLocalSortCap, "the capacity the planner checks buckets against");
-static_assert(kLocalThreads * 20 == kLocalSortCapSmall, "the capacity of the three-per-CU variant");
+static_assert(kLocalThreads * 20 == kLocalSortCapSmall && kLocalThreads * 16 == kLocalSortCapSmallPairs, "the capacities of the three-per-CU variants");
 template <int K>
 constexpr size_t local_lds_words() { return (size_t)kLocalThreads * K + kLocalWaves * (kLocalMaxBins / 2) + 64; }
 
@@ -36,7 +36,9 @@ constexpr size_t local_lds_words() { return (size_t)kLocalThreads * K + kLocalWa
 // (and at most 80 registers): the stage is bound by LDS work that one workgroup's barriers and loads leave idle, so the third
 // resident workgroup is worth about a fifth of its time.  The planner knows the largest bucket and picks (LocalSortParams::skip
 // of the other launch); uniform keys at 2^28 have buckets of 8192 +- 300.
-template <int K>
+// PAIRS: a payload word follows each key (LocalSortParams::vals).  It takes the key's LDS slot in a second round of every pass, as
+// in the global pass kernel: keys to LDS, keys back, payloads to the same slots, payloads back -- two more barriers per pass.
+template <int K, bool PAIRS>
 __device__ __forceinline__ void sort_bucket(const LocalSortParams& p, const uint32_t b)
 {
     constexpr int T = kLocalThreads, W = kLocalWaves, HW = kLocalMaxBins / 2;   // HW: counter words per wave
@@ -61,12 +63,14 @@ __device__ __forceinline__ void sort_bucket(const LocalSortParams& p, const uint
     const uint32_t rows = (size + (uint32_t)T - 1u) / (uint32_t)T;   // uniform, 1 .. K
     const uint32_t wbase = wave * rows * 64u + lane;
 
-    uint32_t key[K], rank[K];
+    uint32_t* const bucket_vals = PAIRS ? p.vals + lo : nullptr;
+    uint32_t key[K], rank[K], val[PAIRS ? K : 1];
 #pragma unroll
     for (int i = 0; i < K; i++) {
         if ((uint32_t)i < rows) {
             const uint32_t pos = wbase + (uint32_t)i * 64u;
             key[i] = pos < size ? bucket[pos] : 0xFFFFFFFFu;
+            if (PAIRS) val[i] = pos < size ? bucket_vals[pos] : 0u;
         }
     }
 
@@ -116,48 +120,99 @@ __device__ __forceinline__ void sort_bucket(const LocalSortParams& p, const uint
         for (int i = 0; i < K; i++) {
             if ((uint32_t)i < rows) {
                 const uint32_t d = (key[i] >> shift) & mask;
-                s_keys[(uint32_t)s_cnt16[wave * kLocalMaxBins + d] + rank[i]] = key[i];
+                const uint32_t pos = (uint32_t)s_cnt16[wave * kLocalMaxBins + d] + rank[i];
+                if (PAIRS) rank[i] = pos;   // the payload's slot
+                s_keys[pos] = key[i];
             }
         }
         __syncthreads();
     };
-    auto read_back = [&]() {   // position order again; the next pass's first barrier keeps its LDS writes behind these reads
+    // after a pass the keys are in LDS in their new order.  `last`: they leave for global memory (linear store); otherwise they
+    // come back into registers in position order (the next pass's first barrier keeps its LDS writes behind these reads).  With
+    // payloads: the same for them, through the same slots, once the keys have been taken out.
+    auto take_out = [&](bool last) {
+        if (last) {
+            for (uint32_t q = tid; q < size; q += (uint32_t)T) bucket[q] = s_keys[q];
+        } else {
 #pragma unroll
-        for (int i = 0; i < K; i++)
-            if ((uint32_t)i < rows) key[i] = s_keys[wbase + (uint32_t)i * 64u];
+            for (int i = 0; i < K; i++)
+                if ((uint32_t)i < rows) key[i] = s_keys[wbase + (uint32_t)i * 64u];
+        }
+        if (PAIRS) {
+            __syncthreads();   // every key has been taken out
+#pragma unroll
+            for (int i = 0; i < K; i++)
+                if ((uint32_t)i < rows) s_keys[rank[i]] = val[i];
+            __syncthreads();
+            if (last) {
+                for (uint32_t q = tid; q < size; q += (uint32_t)T) bucket_vals[q] = s_keys[q];
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; i++)
+                    if ((uint32_t)i < rows) val[i] = s_keys[wbase + (uint32_t)i * 64u];
+            }
+        }
     };
 
     digit_pass(p.shift[0], p.width[0]);
+    take_out(p.width[1] == 0u);
     if (p.width[1]) {
-        read_back();
         digit_pass(p.shift[1], p.width[1]);
+        take_out(p.width[2] == 0u);
     }
     if (p.width[2]) {
-        read_back();
         digit_pass(p.shift[2], p.width[2]);
+        take_out(true);
     }
-    for (uint32_t q = tid; q < size; q += (uint32_t)T) bucket[q] = s_keys[q];
 }
 
+// registers: three workgroups per CU need 80 or fewer (keys K <= 20; pairs K <= 16), two 128; the 16384-pair variant keeps three
+// arrays of 32 and gets 256 (one workgroup per CU: it only ever sees the planner's list of outsized buckets)
+template <int K, bool PAIRS>
+constexpr int local_waves_per_simd() { return (PAIRS ? K <= 16 : K <= 20) ? 6 : (PAIRS ? 2 : 4); }
+
 // one bucket per workgroup
-template <int K>
-__global__ void __launch_bounds__(kLocalThreads, (K <= 20 ? 6 : 4)) local_sort_kernel(const LocalSortParams p)
+template <int K, bool PAIRS>
+__global__ void __launch_bounds__(kLocalThreads, (local_waves_per_simd<K, PAIRS>())) local_sort_kernel(const LocalSortParams p)
 {
     if (p.skip && *p.skip != 0u) return;   // uniform: the plan took the other form
-    sort_bucket<K>(p, blockIdx.x);
+    sort_bucket<K, PAIRS>(p, blockIdx.x);
 }
 
 // The buckets of the planner's list (those above the small variant's capacity), dealt over a small grid: uniform keys leave
 // the list empty, and a launch of 32768 workgroups that each find nothing to do costs 17 us.
-template <int K>
-__global__ void __launch_bounds__(kLocalThreads, (K <= 20 ? 6 : 4)) local_sort_list_kernel(const LocalSortParams p)
+template <int K, bool PAIRS>
+__global__ void __launch_bounds__(kLocalThreads, (local_waves_per_simd<K, PAIRS>())) local_sort_list_kernel(const LocalSortParams p)
 {
     if (p.skip && *p.skip != 0u) return;
     const uint32_t listed = *p.list_count;
     for (uint32_t item = blockIdx.x; item < listed; item += gridDim.x) {
-        sort_bucket<K>(p, p.list[item]);
+        sort_bucket<K, PAIRS>(p, p.list[item]);
         __syncthreads();   // the next bucket reuses the LDS
     }
+}
+
+template <int K, bool PAIRS>
+static hipError_t launch_local_inst(const LocalSortParams& p, hipStream_t stream)
+{
+    constexpr size_t lds_bytes = local_lds_words<K>() * sizeof(uint32_t);
+    if (p.list) {
+        if constexpr (K == 32) {   // the list is the large variant's
+            auto kernel = local_sort_list_kernel<K, PAIRS>;
+            static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (attr != hipSuccess) return attr;
+            hipLaunchKernelGGL(kernel, dim3(512), dim3(kLocalThreads), lds_bytes, stream, p);   // two workgroups per CU walk the list
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+    }
+    auto kernel = local_sort_kernel<K, PAIRS>;
+    if (lds_bytes > 64 * 1024) {
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (attr != hipSuccess) return attr;
+    }
+    hipLaunchKernelGGL(kernel, dim3(p.num_buckets), dim3(kLocalThreads), lds_bytes, stream, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_local_sort(const LocalSortParams& p, hipStream_t stream)
@@ -167,25 +222,13 @@ hipError_t launch_local_sort(const LocalSortParams& p, hipStream_t stream)
     for (int i = 0; i < 3; i++)
         if (p.width[i] > 9 || (p.width[i] && p.shift[i] + p.width[i] > 32)) return hipErrorInvalidValue;
     if ((p.list == nullptr) != (p.list_count == nullptr)) return hipErrorInvalidValue;
-    if (p.small_variant) {
-        if (p.list) return hipErrorInvalidValue;   // the list is the large variant's
-        constexpr size_t lds_bytes = local_lds_words<20>() * sizeof(uint32_t);
-        hipLaunchKernelGGL(local_sort_kernel<20>, dim3(p.num_buckets), dim3(kLocalThreads), lds_bytes, stream, p);
-        return hipGetLastError();
+    if (p.small_variant && p.list) return hipErrorInvalidValue;   // the list is the large variant's
+    if (p.vals) {
+        if (p.small_variant) return launch_local_inst<kLocalSortCapSmallPairs / kLocalThreads, true>(p, stream);
+        return launch_local_inst<32, true>(p, stream);
     }
-    constexpr size_t lds_bytes = local_lds_words<32>() * sizeof(uint32_t);
-    if (p.list) {
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(local_sort_list_kernel<32>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL(local_sort_list_kernel<32>, dim3(512), dim3(kLocalThreads), lds_bytes, stream, p);   // two workgroups per CU walk the list
-        return hipGetLastError();
-    }
-    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(local_sort_kernel<32>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(local_sort_kernel<32>, dim3(p.num_buckets), dim3(kLocalThreads), lds_bytes, stream, p);
-    return hipGetLastError();
+    if (p.small_variant) return launch_local_inst<kLocalSortCapSmall / kLocalThreads, false>(p, stream);
+    return launch_local_inst<32, false>(p, stream);
 }
 
 }  // namespace lsd

@@ -198,9 +198,11 @@ hipError_t launch_tile_offsets(int radix_bits, const uint32_t* hist, uint32_t* l
 // each, by up to three digit passes (shift, width <= 9 bits; width 0 = no pass) run from LDS to LDS.  A bucket above the
 // capacity raises fault bit 3 and is left alone.  *skip != 0 (may be null): the launch does nothing.
 constexpr int kLocalSortCap = 16384;
-constexpr int kLocalSortCapSmall = 10240;   // the three-workgroups-per-CU variant (small_variant)
+constexpr int kLocalSortCapSmall = 10240;   // the three-workgroups-per-CU variant (small_variant), keys only
+constexpr int kLocalSortCapSmallPairs = 8192;   // ... with payloads (a third register per pair)
 struct LocalSortParams {
     uint32_t* keys;
+    uint32_t* vals;              // null: keys only.  Else a payload word per key, permuted with it (stable)
     const uint32_t* bases;
     uint32_t num_buckets;
     uint32_t shift[3], width[3];
@@ -223,14 +225,19 @@ constexpr int kHybridWordLargeCount = 7;  // buckets above the small variant's c
 constexpr int kHybridWordPlanA = 2;       // PassParams::plan of the first global pass (two words)
 constexpr int kHybridWordPlanB = 4;       // ... of the second
 constexpr int kHybridWordLargest = 6;     // the largest bucket (diagnostics)
-constexpr int kHybridWords = 8;
-// field_a[(digit of bits 16-23) * 8 + position region] and bucket[key >> 17] += counts (both zero on entry)
+constexpr int kHybridWordHopeless = 8;    // 1: a sample of the keys already shows a bucket far above the capacity: the upfront read is skipped
+constexpr int kHybridWords = 9;
+// A look at 65536 keys taken at a regular stride: *hopeless = 1 if some bucket holds 0.8 % or more of a workgroup's 1024 samples
+// (its share is 0.003 %): such keys cannot take the hybrid form, and the 0.2-0.3 ms of its upfront read are saved (zeros, a default
+// value, small ranges, few-valued keys).
+hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, uint32_t* hopeless, hipStream_t stream);
+// field_a[(digit of bits 16-23) * 8 + position region] and bucket[key >> 17] += counts (both zero on entry); *skip != 0: nothing
 hipError_t launch_hybrid_histograms(const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field_a, uint32_t* bucket,
-                                    hipStream_t stream);
+                                    const uint32_t* skip, hipStream_t stream);
 // verdict, bucket bases (kHybridBuckets + 1 words), the second pass's (digit, region) counts field_b[2048], plan words
 // ... and large_list[0 .. words[kHybridWordLargeCount]): the buckets of more than kLocalSortCapSmall keys (kHybridBuckets words)
 hipError_t launch_hybrid_plan(const uint32_t* bucket, uint32_t n, uint32_t* bases, uint32_t* field_b, uint32_t* words, uint32_t* large_list,
-                              hipStream_t stream);
+                              uint32_t small_cap, hipStream_t stream);   // small_cap: buckets above it go on the list
 
 // counts64[b] = hist32[b], b < bins (multi-GPU bucket sizes as uint64).
 hipError_t launch_widen_counts(const uint32_t* hist32, uint64_t* counts64, int bins, hipStream_t stream);

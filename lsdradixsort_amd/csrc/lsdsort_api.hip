@@ -409,7 +409,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     // instead of 36.  Tried here for keys-only sorts of the sizes it pays for; the device decides from the exact bucket counts, and
     // every kernel of the form that does NOT run returns at once (plan words in the control block).
     uint32_t* hyb = nullptr;
-    if (plan && radix_bits == 8 && !pairs && !feed && rank_method == lsd::kRankLdsAdd && n >= kHybridMinKeys && n <= kHybridMaxKeys &&
+    if (plan && radix_bits == 8 && more == 0 && !feed && rank_method == lsd::kRankLdsAdd && n >= kHybridMinKeys && n <= kHybridMaxKeys &&
         shape->tile() == 32768 && g_hybrid.load(std::memory_order_relaxed))
         hyb = control + kHybridOffsetWords;
     if (timing) timing->hybrid = hyb ? -1 : 0;   // -1: tried; lsdsort_u32_device_timed reads the device's verdict back
@@ -420,13 +420,16 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             uint32_t* field_a = reinterpret_cast<uint32_t*>(ws + L.hyb_counts);
             uint32_t* field_b = field_a + 256 * L.regions;
             uint32_t* bucket = field_b + 256 * L.regions;
-            LSD_HIP(lsd::launch_hybrid_histograms(d_keys, (uint32_t)n, L.region0, field_a, bucket, stream));
+            LSD_HIP(lsd::launch_hybrid_sample(d_keys, (uint32_t)n, hyb + lsd::kHybridWordHopeless, stream));
+            LSD_HIP(lsd::launch_hybrid_histograms(d_keys, (uint32_t)n, L.region0, field_a, bucket, hyb + lsd::kHybridWordHopeless, stream));
             uint32_t* bases = reinterpret_cast<uint32_t*>(ws + L.hyb_bases);
-            LSD_HIP(lsd::launch_hybrid_plan(bucket, (uint32_t)n, bases, field_b, hyb, bases + lsd::kHybridBuckets + 1, stream));
+            LSD_HIP(lsd::launch_hybrid_plan(bucket, (uint32_t)n, bases, field_b, hyb, bases + lsd::kHybridBuckets + 1,
+                                            (uint32_t)(pairs ? lsd::kLocalSortCapSmallPairs : lsd::kLocalSortCapSmall), stream));
             // the two global passes' region tables: pass A's regions are by position (like any first pass), pass B's by the top
             // bits of A's digit -- exactly what stage 2 builds for two consecutive passes
+            // (no fault word: where the sample or the planner has said no these counts are partial or absent, and nobody uses the tables)
             LSD_HIP(lsd::launch_scan_regions(radix_bits, 2, L.regions, field_a, (uint32_t)n, (uint32_t)shape->tile(), L.region0,
-                                             tables + (size_t)passes * table_words, stream, nullptr, control));
+                                             tables + (size_t)passes * table_words, stream, nullptr, nullptr));
         }
         // stage 1 over [first, first + len): the whole array at once, or chunk by chunk behind the host's copies
         auto histogram = [&](size_t first, size_t len) -> int {
@@ -477,6 +480,9 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
                 PassParams p{};
                 p.in = d_keys;
                 p.out = alt_keys;
+                p.vals_in = d_vals;
+                p.vals_out = alt_vals;
+                p.num_payloads = pairs ? 1u : 0u;
                 p.n = (uint32_t)n;
                 p.shift = (uint32_t)(16 + 8 * g);
                 p.num_tiles = L.rows;
@@ -495,6 +501,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             }
             lsd::LocalSortParams lp{};
             lp.keys = d_keys;
+            lp.vals = d_vals;
             lp.bases = reinterpret_cast<const uint32_t*>(ws + L.hyb_bases);
             lp.num_buckets = (uint32_t)lsd::kHybridBuckets;
             lp.shift[0] = 0; lp.width[0] = 9;      // bits 0-8, then 9-16: the 17 bits below a bucket's own
@@ -1098,7 +1105,8 @@ int lsdsort_rank_scatter_u32_device(const uint32_t* d_in, uint32_t* d_out, const
     return LSDSORT_OK;
 }
 
-int lsdsort_local_sort_u32_device(uint32_t* d_keys, const uint32_t* d_bases, size_t num_buckets, int low_bits, void* hip_stream)
+int lsdsort_local_sort_u32_device(uint32_t* d_keys, uint32_t* d_vals, const uint32_t* d_bases, size_t num_buckets, int low_bits,
+                                  void* hip_stream)
 {
     if (low_bits < 1 || low_bits > 27 || num_buckets > 0xffffffffu) return LSDSORT_ERR_INVALID_ARG;
     if (num_buckets == 0) return LSDSORT_OK;
@@ -1108,6 +1116,7 @@ int lsdsort_local_sort_u32_device(uint32_t* d_keys, const uint32_t* d_bases, siz
     if (!g_device[dev].lds_add_in_lane_order) return LSDSORT_ERR_UNSUPPORTED;   // the local stage ranks by returning LDS adds only
     lsd::LocalSortParams p{};
     p.keys = d_keys;
+    p.vals = d_vals;
     p.bases = d_bases;
     p.num_buckets = (uint32_t)num_buckets;
     const int passes = (low_bits + 8) / 9;                     // digits of at most nine bits, as even as they come

@@ -35,20 +35,27 @@ def test_local_stage_alone(gpu):
         keys = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
         if low_bits == 24:
             keys[: n // 2] &= np.uint32(0xFF0000FF)          # few distinct low values: heavy digits in every local pass
-        d = gpu.to_device(keys)
         db = gpu.to_device(bases)
-        st = gpu.lib().lsdsort_local_sort_u32_device(d.data_ptr(), db.data_ptr(), len(sizes), low_bits, torch.cuda.current_stream().cuda_stream)
-        assert st == 0
-        got = gpu.to_host(d)
         mask = np.uint32((1 << low_bits) - 1)
-        for b, size in enumerate(sizes):
-            lo, hi = int(bases[b]), int(bases[b + 1])
-            part = keys[lo:hi]
-            if size > 16384:
-                assert np.array_equal(got[lo:hi], part), "a bucket above the capacity was touched"
-                continue
-            order = np.argsort(part & mask, kind="stable")
-            assert np.array_equal(got[lo:hi], part[order]), (low_bits, b, size)
+        for with_vals in (False, True):
+            d = gpu.to_device(keys)
+            vals = np.arange(n, dtype=np.uint32) * np.uint32(7) + np.uint32(3)
+            dv = gpu.to_device(vals) if with_vals else None
+            st = gpu.lib().lsdsort_local_sort_u32_device(d.data_ptr(), dv.data_ptr() if with_vals else None, db.data_ptr(), len(sizes), low_bits,
+                                                         torch.cuda.current_stream().cuda_stream)
+            assert st == 0
+            got = gpu.to_host(d)
+            got_v = gpu.to_host(dv) if with_vals else None
+            for b, size in enumerate(sizes):
+                lo, hi = int(bases[b]), int(bases[b + 1])
+                part = keys[lo:hi]
+                if size > 16384:
+                    assert np.array_equal(got[lo:hi], part), "a bucket above the capacity was touched"
+                    continue
+                order = np.argsort(part & mask, kind="stable")
+                assert np.array_equal(got[lo:hi], part[order]), (low_bits, b, size, with_vals)
+                if with_vals:
+                    assert np.array_equal(got_v[lo:hi], vals[lo:hi][order]), (low_bits, b, size, "payload order = stable order")
 
 
 @pytest.mark.parametrize("log2n,extra", [(27, 0), (27, 12345), (28, 777)])
@@ -96,8 +103,42 @@ def test_hybrid_equals_torch_sort_and_the_four_pass_form(gpu, log2n, extra):
     assert taken["half_zero"] == 0 and taken["small_range"] == 0 and taken["one_bucket_just_too_large"] == 0, taken
 
 
+@pytest.mark.parametrize("n", [(1 << 27) + 4321])
+def test_hybrid_pairs_are_stable(gpu, n):
+    """Key/value pairs through the hybrid form (BASELINE configs[4]'s size): payload = input position, so the output must be
+    torch's STABLE sort -- on keys the device takes (uniform; duplicates inside the buckets: 20 live bits below the bucket's) and on
+    keys it refuses (half zeros); the same with the form off."""
+    import torch
+
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(77)
+    base = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda", generator=gen)
+    vals0 = torch.arange(n, dtype=torch.int32, device="cuda")
+    ws = gpu.alloc_workspace(n, 8, True)
+    shapes = {
+        "uniform": (lambda: base.clone(), 1),
+        "duplicates_in_buckets": (lambda: _i32(_u64(base) & 0xFFFE0F0F), 1),
+        "half_zero": (lambda: _i32(torch.where(((_u64(base) >> 13) & 1) != 0, _u64(base), torch.zeros_like(_u64(base)))), 0),
+    }
+    for name, (make, expect_hybrid) in shapes.items():
+        keys = make()
+        expect = torch.sort(_u64(keys), stable=True)
+        for on in (True, False):
+            gpu.set_hybrid(on)
+            try:
+                d, v = keys.clone(), vals0.clone()
+                tm = gpu.GPULSDRadixSortTimed(d, 8, d_vals=v, workspace=ws)
+                assert tm["hybrid"] == (expect_hybrid if on else 0), (name, on, tm["hybrid"])
+                assert torch.equal(_u64(d), expect.values), (name, on)
+                assert torch.equal(v.to(torch.int64), expect.indices), (name, on, "order among equal keys")
+                assert gpu.lib().lsdsort_check_device(ws.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+            finally:
+                gpu.set_hybrid(True)
+        del keys, expect
+
+
 def test_hybrid_is_not_tried_outside_its_range(gpu):
-    """Below 2^27 keys, with payloads, at 4-bit digits and for typed keys the four-pass form runs (lsdsort_timing.hybrid = 0)."""
+    """Below 2^27 keys, at 4-bit digits, with more than one payload array and for typed keys the four-pass form runs."""
     import torch
 
     n = (1 << 26) + 5
@@ -107,8 +148,5 @@ def test_hybrid_is_not_tried_outside_its_range(gpu):
     assert tm["hybrid"] == 0 and torch.equal(_u64(d), expect)
     n = (1 << 27) + 3
     d = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda")
-    v = torch.arange(n, dtype=torch.int32, device="cuda")
-    tm = gpu.GPULSDRadixSortTimed(d.clone(), 8, d_vals=v)
-    assert tm["hybrid"] == 0
     tm = gpu.GPULSDRadixSortTimed(d.clone(), 4)
     assert tm["hybrid"] == 0
