@@ -157,8 +157,11 @@ LSDSORT_API int lsdsort_wide_check_device(void* d_workspace, size_t n, int radix
                                           void* hip_stream);
 
 /* After the stream has drained: LSDSORT_OK, or LSDSORT_ERR_DEVICE_FAULT if a kernel of the
- * last sort on this workspace gave up a bounded spin (never expected; the output is then
- * undefined).  Synchronises hip_stream. */
+ * last sort on this workspace gave up a bounded spin or refused destinations outside the output
+ * (never expected; the output is then undefined).  Synchronises hip_stream.  With LSDSORT_REPROBE=1
+ * in the environment (always in the diagnostic build) the device probe behind the default rank form
+ * (lsdsort_set_rank_method) is run again here; a failure is reported as LSDSORT_ERR_DEVICE_FAULT and
+ * the library uses the mask forms from then on. */
 LSDSORT_API int lsdsort_check_device(void* d_workspace, void* hip_stream);
 
 /* Per-kernel device times of one sort, by hipEvent on hip_stream (the reference times only

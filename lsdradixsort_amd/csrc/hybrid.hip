@@ -34,37 +34,40 @@ constexpr int kHybridVpt = 4;              // 16-byte vectors per thread per gro
 // in LDS (one workgroup doing all of them waits 0.12 ms for its own 65536 cache lines; global counters melt on constant keys:
 // 65536 returning atomics on one word took 0.6 ms).  A bucket's share of a workgroup's 1024 samples is 1/32 of a key: eight in one
 // bucket -- 0.8 % of all keys, two hundred times a bucket's share -- raise the flag.
-__global__ void __launch_bounds__(1024) hybrid_sample_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ hopeless)
+__global__ void __launch_bounds__(1024) hybrid_sample_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t bucket_shift,
+                                                             uint32_t* __restrict__ hopeless)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];   // [kHybridBuckets]
     constexpr uint32_t kSamples = 65536;
     const unsigned long long step = n / kSamples;   // n >= 2^27: at least 2048
     const uint32_t tid = threadIdx.x;
     const uint32_t k = keys[(size_t)((unsigned long long)(blockIdx.x * 1024u + tid) * step)];
-    for (uint32_t j = tid; j < (uint32_t)kHybridBuckets; j += 1024) s_cnt[j] = 0;
+    for (uint32_t j = tid; j < (1u << (32u - bucket_shift)); j += 1024) s_cnt[j] = 0;
     __syncthreads();
-    if (atomicAdd(&s_cnt[k >> kHybridBucketShift], 1u) + 1u >= 8u) *hopeless = 1u;
+    if (atomicAdd(&s_cnt[k >> bucket_shift], 1u) + 1u >= 8u) *hopeless = 1u;
 }
 
-hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, uint32_t* hopeless, hipStream_t stream)
+hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bits, uint32_t* hopeless, hipStream_t stream)
 {
-    if (n < 65536u * 64u) return hipErrorInvalidValue;
+    if (n < 65536u * 64u || bucket_bits < 11 || (1 << bucket_bits) > kHybridBuckets) return hipErrorInvalidValue;
+    const uint32_t bucket_shift = 32u - (uint32_t)bucket_bits;
     constexpr size_t lds_bytes = (size_t)kHybridBuckets * sizeof(uint32_t);
     static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_sample_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(hybrid_sample_kernel, dim3(64), dim3(1024), lds_bytes, stream, keys, n, hopeless);
+    hipLaunchKernelGGL(hybrid_sample_kernel, dim3(64), dim3(1024), lds_bytes, stream, keys, n, bucket_shift, hopeless);
     return hipGetLastError();
 }
 
 __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                                uint32_t region0_keys, uint32_t* __restrict__ field_a,
                                                                                uint32_t* __restrict__ bucket, uint32_t vec_chunks,
-                                                                               const uint32_t* __restrict__ skip)
+                                                                               const uint32_t* __restrict__ skip, uint32_t bucket_shift)
 {
     if (skip && *skip != 0u) return;   // uniform: the sample has ruled the hybrid form out (the planner then sees no counts: not ok)
     constexpr int T = kHybridHistThreads, CA = kHybridCopiesA, VPT = kHybridVpt;
-    constexpr uint32_t FA = 2048, NB = kHybridBuckets;
+    constexpr uint32_t FA = 2048;
+    const uint32_t NB = 1u << (32u - bucket_shift);   // at most kHybridBuckets (the LDS is sized for that)
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     uint32_t* const s_a = s_mem;                 // [region][digit][CA], region-major: a wave's lanes share the region
     uint32_t* const s_b = s_mem + FA * CA;       // [NB]
@@ -75,7 +78,7 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
     auto slot_a = [&](uint32_t k, uint32_t region0) -> uint32_t { return ((region0 << 8) | ((k >> 16) & 0xFFu)) * CA; };
     auto count_plain = [&](uint32_t k, uint32_t region0) {
         atomicAdd(&s_a[slot_a(k, region0) + copy], 1u);
-        atomicAdd(&s_b[k >> kHybridBucketShift], 1u);
+        atomicAdd(&s_b[k >> bucket_shift], 1u);
     };
     uint32_t key1 = 0, key2 = 0;   // sticky heavy-key candidates (uniform)
     bool have1 = false, have2 = false;
@@ -124,11 +127,11 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
                 if (lane == 0) {
                     if (n1) {
                         atomicAdd(&s_a[slot_a(key1, region0)], n1);
-                        atomicAdd(&s_b[key1 >> kHybridBucketShift], n1);
+                        atomicAdd(&s_b[key1 >> bucket_shift], n1);
                     }
                     if (n2) {
                         atomicAdd(&s_a[slot_a(key2, region0)], n2);
-                        atomicAdd(&s_b[key2 >> kHybridBucketShift], n2);
+                        atomicAdd(&s_b[key2 >> bucket_shift], n2);
                     }
                 }
                 continue;
@@ -153,12 +156,12 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
 #pragma unroll
                     for (int q = 0; q < 4; q++) atomicAdd(&s_a[slot_a(k4[q], region0) + copy], 1u);
                 }
-                const uint32_t b0 = k4[0] >> kHybridBucketShift, b_first = (uint32_t)__builtin_amdgcn_readfirstlane(b0);
+                const uint32_t b0 = k4[0] >> bucket_shift, b_first = (uint32_t)__builtin_amdgcn_readfirstlane(b0);
                 if ((uint32_t)__builtin_popcountll(__ballot(b0 == b_first)) >= 16u) {
                     uint32_t held = 0;
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const uint32_t sb = k4[q] >> kHybridBucketShift;
+                        const uint32_t sb = k4[q] >> bucket_shift;
                         const bool h = sb == b_first;
                         held += (uint32_t)__builtin_popcountll(__ballot(h));
                         if (!h) atomicAdd(&s_b[sb], 1u);
@@ -166,7 +169,7 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
                     if (lane == 0) atomicAdd(&s_b[b_first], held);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) atomicAdd(&s_b[k4[q] >> kHybridBucketShift], 1u);
+                    for (int q = 0; q < 4; q++) atomicAdd(&s_b[k4[q] >> bucket_shift], 1u);
                 }
             }
         }
@@ -218,8 +221,9 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
 }
 
 hipError_t launch_hybrid_histograms(const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field_a, uint32_t* bucket,
-                                    const uint32_t* skip, hipStream_t stream)
+                                    int bucket_bits, const uint32_t* skip, hipStream_t stream)
 {
+    if (bucket_bits < 11 || (1 << bucket_bits) > kHybridBuckets) return hipErrorInvalidValue;
     constexpr int T = kHybridHistThreads;
     constexpr size_t lds_bytes = (size_t)(2048 * kHybridCopiesA + kHybridBuckets) * sizeof(uint32_t);
     static_assert(lds_bytes <= 160 * 1024, "one workgroup per CU");
@@ -233,18 +237,18 @@ hipError_t launch_hybrid_histograms(const uint32_t* keys, uint32_t n, uint32_t r
     uint32_t blocks = aligned ? (vec_chunks + kHybridVpt - 1) / kHybridVpt : (n + T * 16 - 1) / (T * 16);
     if (blocks > 256) blocks = 256;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(hybrid_histograms_kernel, dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks, skip);
+    hipLaunchKernelGGL(hybrid_histograms_kernel, dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks, skip, 32u - (uint32_t)bucket_bits);
     return hipGetLastError();
 }
 
 // The planner: one workgroup.  From the bucket counts: the verdict (largest bucket <= kLocalSortCap and the counts sum to n),
 // the buckets' bases (exclusive scan, kHybridBuckets + 1 words), the second global pass's (digit, region) counts -- region =
 // top three bits of the first pass's digit, i.e. sixteen consecutive buckets per cell -- and the plan words the other kernels read.
+template <int PER>   // consecutive buckets per thread = two (digit, region) cells: 32 for 2^15 buckets, 16 for 2^14
 __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __restrict__ bucket, uint32_t n, uint32_t* __restrict__ bases,
                                                            uint32_t* __restrict__ field_b, uint32_t* __restrict__ words,
                                                            uint32_t* __restrict__ large_list, uint32_t small_cap)
 {
-    constexpr uint32_t PER = kHybridBuckets / 1024;   // 32 consecutive buckets per thread = two (digit, region) cells
     __shared__ uint32_t s_wave[16], s_max[16], s_large;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) s_large = 0;
@@ -291,7 +295,7 @@ __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __res
         run += cnt[j];
     }
     if (tid == 0) {
-        bases[kHybridBuckets] = n;
+        bases[1024 * PER] = n;
         const uint32_t ok = (largest <= (uint32_t)kLocalSortCap && total == n) ? 1u : 0u;
         words[kHybridWordOk] = ok;            // the ordinary form's kernels return at once when this is set
         words[kHybridWordSkipLocal] = ok ^ 1u;
@@ -304,10 +308,15 @@ __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __res
     }
 }
 
-hipError_t launch_hybrid_plan(const uint32_t* bucket, uint32_t n, uint32_t* bases, uint32_t* field_b, uint32_t* words, uint32_t* large_list,
-                              uint32_t small_cap, hipStream_t stream)
+hipError_t launch_hybrid_plan(const uint32_t* bucket, uint32_t n, int bucket_bits, uint32_t* bases, uint32_t* field_b, uint32_t* words,
+                              uint32_t* large_list, uint32_t small_cap, hipStream_t stream)
 {
-    hipLaunchKernelGGL(hybrid_plan_kernel, dim3(1), dim3(1024), 0, stream, bucket, n, bases, field_b, words, large_list, small_cap);
+    if (bucket_bits == 15)
+        hipLaunchKernelGGL(hybrid_plan_kernel<32>, dim3(1), dim3(1024), 0, stream, bucket, n, bases, field_b, words, large_list, small_cap);
+    else if (bucket_bits == 14)
+        hipLaunchKernelGGL(hybrid_plan_kernel<16>, dim3(1), dim3(1024), 0, stream, bucket, n, bases, field_b, words, large_list, small_cap);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

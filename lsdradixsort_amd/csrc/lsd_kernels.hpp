@@ -216,8 +216,10 @@ struct LocalSortParams {
 hipError_t launch_local_sort(const LocalSortParams& p, hipStream_t stream);
 
 // ---- the hybrid form's upfront read and planner (hybrid.hip) ------------------------------------------------------------
-constexpr int kHybridBucketShift = 17;                       // a bucket = the keys that agree on their top 15 bits
-constexpr int kHybridBuckets = 1 << (32 - kHybridBucketShift);
+// A bucket = the keys that agree on their top `bucket_bits` bits: 15 for 2^27 keys and more, 14 below (the average bucket stays
+// between 4096 and 14648 keys).  Every table is sized for 2^15.
+constexpr int kHybridBuckets = 1 << 15;
+inline constexpr int hybrid_bucket_bits(size_t n) { return n >= ((size_t)1 << 27) ? 15 : 14; }
 // plan words (uint32, in the workspace's control block): written by the planner, read by every kernel of either form
 constexpr int kHybridWordOk = 0;          // 1: the hybrid form runs (the ordinary form's kernels return at once)
 constexpr int kHybridWordSkipLocal = 1;   // 1: the local stage returns at once (both launches)
@@ -230,14 +232,15 @@ constexpr int kHybridWords = 9;
 // A look at 65536 keys taken at a regular stride: *hopeless = 1 if some bucket holds 0.8 % or more of a workgroup's 1024 samples
 // (its share is 0.003 %): such keys cannot take the hybrid form, and the 0.2-0.3 ms of its upfront read are saved (zeros, a default
 // value, small ranges, few-valued keys).
-hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, uint32_t* hopeless, hipStream_t stream);
-// field_a[(digit of bits 16-23) * 8 + position region] and bucket[key >> 17] += counts (both zero on entry); *skip != 0: nothing
+hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bits, uint32_t* hopeless, hipStream_t stream);
+// field_a[(digit of bits 16-23) * 8 + position region] and bucket[key >> (32 - bucket_bits)] += counts (both zero on entry);
+// *skip != 0: nothing
 hipError_t launch_hybrid_histograms(const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field_a, uint32_t* bucket,
-                                    const uint32_t* skip, hipStream_t stream);
-// verdict, bucket bases (kHybridBuckets + 1 words), the second pass's (digit, region) counts field_b[2048], plan words
-// ... and large_list[0 .. words[kHybridWordLargeCount]): the buckets of more than kLocalSortCapSmall keys (kHybridBuckets words)
-hipError_t launch_hybrid_plan(const uint32_t* bucket, uint32_t n, uint32_t* bases, uint32_t* field_b, uint32_t* words, uint32_t* large_list,
-                              uint32_t small_cap, hipStream_t stream);   // small_cap: buckets above it go on the list
+                                    int bucket_bits, const uint32_t* skip, hipStream_t stream);
+// verdict, bucket bases (2^bucket_bits + 1 words), the second pass's (digit, region) counts field_b[2048], plan words
+// ... and large_list[0 .. words[kHybridWordLargeCount]): the buckets of more than small_cap keys (up to 2^bucket_bits words)
+hipError_t launch_hybrid_plan(const uint32_t* bucket, uint32_t n, int bucket_bits, uint32_t* bases, uint32_t* field_b, uint32_t* words,
+                              uint32_t* large_list, uint32_t small_cap, hipStream_t stream);
 
 // counts64[b] = hist32[b], b < bins (multi-GPU bucket sizes as uint64).
 hipError_t launch_widen_counts(const uint32_t* hist32, uint64_t* counts64, int bins, hipStream_t stream);

@@ -45,10 +45,11 @@ std::atomic<int> g_hybrid{[] {                                          // lsdso
     const char* e = getenv("LSDSORT_HYBRID");
     return (e && e[0] == '0') ? 0 : 1;
 }()};
-// The hybrid form is tried for keys-only 8-bit-digit sorts whose AVERAGE top-15-bit bucket leaves the local stage room: 4096 ..
-// 14648 keys per bucket (below, 32768 workgroups of almost nothing cost more than the two passes they replace; above, the largest
-// bucket of even uniform keys nears the 16384-key capacity).  Whether it RUNS is decided on the device from the exact bucket counts.
-constexpr size_t kHybridMinKeys = (size_t)1 << 27;
+// The hybrid form is tried for 8-bit-digit sorts whose AVERAGE bucket (top 15 bits from 2^27 keys, top 14 below) leaves the local
+// stage room: 4096 .. 14648 keys per bucket (below, tens of thousands of workgroups of almost nothing cost more than the two passes
+// they replace; above, the largest bucket of even uniform keys nears the 16384-key capacity).  Whether it RUNS is decided on the
+// device from the exact bucket counts.
+constexpr size_t kHybridMinKeys = (size_t)1 << 26;
 constexpr size_t kHybridMaxKeys = (size_t)480 * 1000 * 1000;
 std::atomic<int> g_skip_dead_passes{[] {                                // lsdsort_set_pass_skipping; LSDSORT_PASS_SKIPPING=0 starts it off
     const char* e = getenv("LSDSORT_PASS_SKIPPING");
@@ -410,7 +411,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     // every kernel of the form that does NOT run returns at once (plan words in the control block).
     uint32_t* hyb = nullptr;
     if (plan && radix_bits == 8 && more == 0 && !feed && rank_method == lsd::kRankLdsAdd && n >= kHybridMinKeys && n <= kHybridMaxKeys &&
-        shape->tile() == 32768 && g_hybrid.load(std::memory_order_relaxed))
+        (n >> lsd::hybrid_bucket_bits(n)) <= 14648 && shape->tile() == 32768 && g_hybrid.load(std::memory_order_relaxed))
         hyb = control + kHybridOffsetWords;
     if (timing) timing->hybrid = hyb ? -1 : 0;   // -1: tried; lsdsort_u32_device_timed reads the device's verdict back
     if (algorithm == LSDSORT_ALGO_ONESWEEP) {
@@ -420,10 +421,11 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             uint32_t* field_a = reinterpret_cast<uint32_t*>(ws + L.hyb_counts);
             uint32_t* field_b = field_a + 256 * L.regions;
             uint32_t* bucket = field_b + 256 * L.regions;
-            LSD_HIP(lsd::launch_hybrid_sample(d_keys, (uint32_t)n, hyb + lsd::kHybridWordHopeless, stream));
-            LSD_HIP(lsd::launch_hybrid_histograms(d_keys, (uint32_t)n, L.region0, field_a, bucket, hyb + lsd::kHybridWordHopeless, stream));
+            const int bb = lsd::hybrid_bucket_bits(n);
+            LSD_HIP(lsd::launch_hybrid_sample(d_keys, (uint32_t)n, bb, hyb + lsd::kHybridWordHopeless, stream));
+            LSD_HIP(lsd::launch_hybrid_histograms(d_keys, (uint32_t)n, L.region0, field_a, bucket, bb, hyb + lsd::kHybridWordHopeless, stream));
             uint32_t* bases = reinterpret_cast<uint32_t*>(ws + L.hyb_bases);
-            LSD_HIP(lsd::launch_hybrid_plan(bucket, (uint32_t)n, bases, field_b, hyb, bases + lsd::kHybridBuckets + 1,
+            LSD_HIP(lsd::launch_hybrid_plan(bucket, (uint32_t)n, bb, bases, field_b, hyb, bases + lsd::kHybridBuckets + 1,
                                             (uint32_t)(pairs ? lsd::kLocalSortCapSmallPairs : lsd::kLocalSortCapSmall), stream));
             // the two global passes' region tables: pass A's regions are by position (like any first pass), pass B's by the top
             // bits of A's digit -- exactly what stage 2 builds for two consecutive passes
@@ -503,9 +505,10 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             lp.keys = d_keys;
             lp.vals = d_vals;
             lp.bases = reinterpret_cast<const uint32_t*>(ws + L.hyb_bases);
-            lp.num_buckets = (uint32_t)lsd::kHybridBuckets;
-            lp.shift[0] = 0; lp.width[0] = 9;      // bits 0-8, then 9-16: the 17 bits below a bucket's own
-            lp.shift[1] = 9; lp.width[1] = 8;
+            const int bb = lsd::hybrid_bucket_bits(n);
+            lp.num_buckets = 1u << bb;
+            lp.shift[0] = 0; lp.width[0] = 9;      // bits 0-8, then 9-16 (or 9-17): the 17 (18) bits below a bucket's own
+            lp.shift[1] = 9; lp.width[1] = (uint32_t)(32 - bb - 9);
             lp.skip = hyb + lsd::kHybridWordSkipLocal;
             lp.fault = control;
             if (ev) LSD_TRY(ev->mark());
@@ -969,8 +972,31 @@ int lsdsort_keys_device(void* d_keys, uint32_t* d_vals, void* d_workspace, size_
 int lsdsort_check_device(void* d_workspace, void* hip_stream)
 {
     if (!d_workspace) return LSDSORT_ERR_WORKSPACE;
-    LSD_TRY(check_device_ready());
-    return read_fault(d_workspace, static_cast<hipStream_t>(hip_stream));
+    int dev = 0;
+    LSD_TRY(check_device_ready(&dev));
+    const int status = read_fault(d_workspace, static_cast<hipStream_t>(hip_stream));
+    // The default rank form rests on a probed hardware property (lane-ordered returning LDS adds, rank_scatter.hpp); the probe
+    // runs once per device.  Diagnostic builds, and any build with LSDSORT_REPROBE=1 in the environment, run it AGAIN whenever a
+    // caller checks a sort: a device that stops honouring the property is reported here (and the library falls back to the mask
+    // forms from then on) instead of silently mis-ordering equal digits.
+#ifdef LSD_FAULT_INJECT
+    constexpr bool always = true;
+#else
+    constexpr bool always = false;
+#endif
+    static const bool by_env = [] {
+        const char* e = getenv("LSDSORT_REPROBE");
+        return e && e[0] == '1';
+    }();
+    if (status == LSDSORT_OK && (always || by_env) && g_device[dev].lds_add_in_lane_order) {
+        bool ok = false;
+        LSD_HIP(lsd::probe_lds_add_lane_order(&ok, static_cast<hipStream_t>(hip_stream)));
+        if (!ok) {
+            g_device[dev].lds_add_in_lane_order = false;
+            return LSDSORT_ERR_DEVICE_FAULT;
+        }
+    }
+    return status;
 }
 
 int lsdsort_u32_device_timed(uint32_t* d_keys, uint32_t* d_vals, void* d_workspace, size_t workspace_bytes, size_t n,

@@ -58,11 +58,13 @@ def test_local_stage_alone(gpu):
                     assert np.array_equal(got_v[lo:hi], vals[lo:hi][order]), (low_bits, b, size, "payload order = stable order")
 
 
-@pytest.mark.parametrize("log2n,extra", [(27, 0), (27, 12345), (28, 777)])
+@pytest.mark.parametrize("log2n,extra", [(26, 999), (27, 0), (27, 12345), (28, 777)])
 def test_hybrid_equals_torch_sort_and_the_four_pass_form(gpu, log2n, extra):
     import torch
 
     n = (1 << log2n) + extra
+    bb = 15 if log2n >= 27 else 14          # bucket = the top bb bits (lsd_kernels.hpp hybrid_bucket_bits)
+    sh, low = 32 - bb, (1 << (32 - bb)) - 1
     gen = torch.Generator(device="cuda")
     gen.manual_seed(4000 + log2n + extra)
     base = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda", generator=gen)
@@ -73,13 +75,13 @@ def test_hybrid_equals_torch_sort_and_the_four_pass_form(gpu, log2n, extra):
         "low_bits_dead": lambda: _i32(_u64(base) & 0xFFFFFE00),                       # the local stage's first digit constant
         "half_zero": lambda: _i32(torch.where(((_u64(base) >> 13) & 1) != 0, _u64(base), torch.zeros_like(_u64(base)))),   # bucket 0 too large
         "small_range": lambda: _i32(_u64(base) & 0x000FFFFF),                         # one bucket holds everything
-        "one_bucket_just_too_large": lambda: _i32(torch.cat([_u64(base[: n - 16385]), (_u64(base[:16385]) & 0x1FFFF) | (5 << 17)])),
+        "one_bucket_just_too_large": lambda: _i32(torch.cat([_u64(base[: n - 16385]), (_u64(base[:16385]) & low) | (5 << sh)])),
         # fifty buckets between the two capacities of the local stage (10240 < size <= 16384): the planner's list, walked by
-        # the large variant, while the small variant takes the other 32718
+        # the large variant, while the small variant takes the others
         "fifty_buckets_above_the_small_capacity": lambda: _i32(torch.cat([
-            _u64(base[: n - 50 * hot]), (_u64(base[: 50 * hot]) & 0x1FFFF) | ((torch.arange(50 * hot, device="cuda") // hot * 601 + 77) << 17)])),
+            _u64(base[: n - 50 * hot]), (_u64(base[: 50 * hot]) & low) | ((torch.arange(50 * hot, device="cuda") // hot * 301 + 77) << sh)])),
     }
-    hot = 16000 - (n >> 15) - 700          # a hot bucket: its share of the uniform keys plus this many, under 16384 in all
+    hot = 16000 - (n >> bb) - 700          # a hot bucket: its share of the uniform keys plus this many, under 16384 in all
     taken = {}
     for name, make in shapes.items():
         keys = make()
@@ -99,11 +101,11 @@ def test_hybrid_equals_torch_sort_and_the_four_pass_form(gpu, log2n, extra):
             gpu.set_hybrid(True)
         del keys, expect, d, d2
     assert taken["uniform"] == 1 and taken["sorted"] == 1 and taken["low_bits_dead"] == 1, taken
-    assert taken["fifty_buckets_above_the_small_capacity"] == (1 if hot > 10240 - (n >> 15) else taken["fifty_buckets_above_the_small_capacity"]), taken
+    assert taken["fifty_buckets_above_the_small_capacity"] == (1 if hot > 10240 - (n >> bb) else taken["fifty_buckets_above_the_small_capacity"]), taken
     assert taken["half_zero"] == 0 and taken["small_range"] == 0 and taken["one_bucket_just_too_large"] == 0, taken
 
 
-@pytest.mark.parametrize("n", [(1 << 27) + 4321])
+@pytest.mark.parametrize("n", [(1 << 26) + 77, (1 << 27) + 4321])
 def test_hybrid_pairs_are_stable(gpu, n):
     """Key/value pairs through the hybrid form (BASELINE configs[4]'s size): payload = input position, so the output must be
     torch's STABLE sort -- on keys the device takes (uniform; duplicates inside the buckets: 20 live bits below the bucket's) and on
@@ -138,10 +140,10 @@ def test_hybrid_pairs_are_stable(gpu, n):
 
 
 def test_hybrid_is_not_tried_outside_its_range(gpu):
-    """Below 2^27 keys, at 4-bit digits, with more than one payload array and for typed keys the four-pass form runs."""
+    """Below 2^26 keys, at 4-bit digits, with more than one payload array and for typed keys the four-pass form runs."""
     import torch
 
-    n = (1 << 26) + 5
+    n = (1 << 26) - 5
     d = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda")
     expect = torch.sort(_u64(d)).values
     tm = gpu.GPULSDRadixSortTimed(d, 8)

@@ -7,6 +7,7 @@ set -o pipefail
 TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
+rm -rf $OUT   # files of an earlier run with the same tag would be averaged in
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name, rocprof args...
