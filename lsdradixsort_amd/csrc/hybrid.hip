@@ -25,23 +25,25 @@ constexpr int kHybridHistThreads = 1024;
 constexpr int kHybridCopiesA = 2;          // lane-class copies of the first pass's 2048 (region, digit) counters
 constexpr int kHybridVpt = 4;              // 16-byte vectors per thread per group
 
-// Upfront read of the hybrid form.  fieldA[(digit of bits 16-23) * 8 + position region] and bucket[key >> 17] (global, zero on
+// Upfront read of the hybrid form.  fieldA[(digit of bits 16-23) * 8 + position region] and bucket[key >> bucket_shift] (global, zero on
 // entry) receive the counts.  Grid-stride over chunks of 4096 keys, two register buffers, non-temporal loads (as stage 1 of the
 // ordinary form, aux_kernels.hip).  Heavy values are handled as there: keys equal to a sticky candidate value (zeros, a default
 // value) are counted by ballot for both fields at once, and per field the holders of the first lane's counter are counted by
 // ballot when sixteen lanes or more share it (sorted or constant input, dead digits, small ranges).
 // The sample: 65536 keys at a regular stride, 1024 per workgroup over 64 workgroups, each workgroup counting ITS samples by bucket
 // in LDS (one workgroup doing all of them waits 0.12 ms for its own 65536 cache lines; global counters melt on constant keys:
-// 65536 returning atomics on one word took 0.6 ms).  A bucket's share of a workgroup's 1024 samples is 1/32 of a key: eight in one
+// 65536 returning atomics on one word took 0.6 ms).  A bucket's share of a workgroup's 1024 samples is 1/32 .. 1/16 of a key: eight in one
 // bucket -- 0.8 % of all keys, two hundred times a bucket's share -- raise the flag.
 __global__ void __launch_bounds__(1024) hybrid_sample_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t bucket_shift,
                                                              uint32_t* __restrict__ hopeless)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];   // [kHybridBuckets]
     constexpr uint32_t kSamples = 65536;
-    const unsigned long long step = n / kSamples;   // n >= 2^27: at least 2048
+    const unsigned long long step = n / kSamples;   // n >= 2^26: at least 1024
     const uint32_t tid = threadIdx.x;
-    const uint32_t k = keys[(size_t)((unsigned long long)(blockIdx.x * 1024u + tid) * step)];
+    // interleaved: workgroup w takes samples w, w + 64, ... so each sees the WHOLE array at 64 x step -- a contiguous run of one
+    // bucket's keys (sorted input, a bucket of 11000 keys stored together) is spread over the workgroups instead of filling one
+    const uint32_t k = keys[(size_t)((unsigned long long)(tid * 64u + blockIdx.x) * step)];
     for (uint32_t j = tid; j < (1u << (32u - bucket_shift)); j += 1024) s_cnt[j] = 0;
     __syncthreads();
     if (atomicAdd(&s_cnt[k >> bucket_shift], 1u) + 1u >= 8u) *hopeless = 1u;
