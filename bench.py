@@ -476,13 +476,16 @@ def main(argv=None):
         stage_ms["sort_algorithmic_gbs"] = round(sort_bytes / (ms_per_step * 1e-3) / 1e9, 1) if not distributed else None
         stage_ms["sort_roofline_frac"] = round(sort_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if not distributed else None
         if stage_ms["hybrid_form"] and not distributed:
-            # what the sort that ran really moves: one counting read, two global passes, one local stage = 4 + 3 x 8 B/key
-            moved = 28 * n
-            stage_ms["sort_moved_bytes_per_key"] = 28
+            # what the sort that ran really moves: one counting read, 16 / r global passes, one local stage = 4 + (16 / r + 1) x 8 B/key
+            per_item = 2 if args.pairs else 1
+            moved_per_key = 4 + (16 // r + 1) * 8 * per_item
+            moved = moved_per_key * n
+            stage_ms["sort_moved_bytes_per_key"] = moved_per_key
             stage_ms["sort_moved_gbs"] = round(moved / (ms_per_step * 1e-3) / 1e9, 1)
             stage_ms["sort_moved_frac_of_peak"] = round(moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            stage_ms["accounting"] = ("sort_roofline_frac prices the sort at SURVEY 8d's algorithmic 36 B/key (a four-pass 8-bit LSD sort); the hybrid "
-                                      "form moves 28 B/key (sort_moved_*): the last two digits are sorted inside the CUs' LDS")
+            stage_ms["accounting"] = (f"sort_roofline_frac prices the sort at SURVEY 8d's algorithmic {sort_bytes // n} B/key (an LSD sort of {passes} "
+                                      f"passes through HBM); the hybrid form moves {moved_per_key} B/key (sort_moved_*): the low 16 bits are sorted "
+                                      "inside the CUs' LDS")
         roofline["rank_method"] = lsd.rank_method(r)
         if not distributed and not args.no_live_traffic and args.algorithm == "onesweep" and args.tile_config < 0:
             live = live_pmc_traffic(r, args.pairs, log2_keys)

@@ -61,14 +61,18 @@ hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bit
     return hipGetLastError();
 }
 
+template <int R>   // digit width of the global passes: 8 or 4
 __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                                uint32_t region0_keys, uint32_t* __restrict__ field_a,
                                                                                uint32_t* __restrict__ bucket, uint32_t vec_chunks,
                                                                                const uint32_t* __restrict__ skip, uint32_t bucket_shift)
 {
     if (skip && *skip != 0u) return;   // uniform: the sample has ruled the hybrid form out (the planner then sees no counts: not ok)
-    constexpr int T = kHybridHistThreads, CA = kHybridCopiesA, VPT = kHybridVpt;
-    constexpr uint32_t FA = 2048;
+    // 8-bit digits: the first pass's field, [8 position regions][256 digits], two lane-class copies.  4-bit digits: the JOINT field
+    // of the first two passes, [16 position regions][bits 16-23] in one copy -- the same 4096 words and the same two LDS adds per
+    // key; the planner sums it to pass A's [digit][region] and pass B's [digit][A's digit].
+    constexpr int T = kHybridHistThreads, CA = R == 8 ? kHybridCopiesA : 1, VPT = kHybridVpt;
+    constexpr uint32_t FA = R == 8 ? 2048 : 4096;
     const uint32_t NB = 1u << (32u - bucket_shift);   // at most kHybridBuckets (the LDS is sized for that)
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     uint32_t* const s_a = s_mem;                 // [region][digit][CA], region-major: a wave's lanes share the region
@@ -209,11 +213,15 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
     for (size_t i = (size_t)full_chunks * (T * 4) + (size_t)blockIdx.x * T + tid; i < n; i += (size_t)gridDim.x * T)
         count_plain(keys[i], (uint32_t)(i / region0_keys));
     __syncthreads();
-    for (uint32_t j = tid; j < FA; j += T) {   // global layout [digit][region], LDS layout [region][digit][copy]
-        const uint32_t d = j >> 3, x = j & 7u;
+    for (uint32_t j = tid; j < FA; j += T) {
         uint32_t cnt = 0;
+        if (R == 8) {   // global layout [digit][region], LDS layout [region][digit][copy]
+            const uint32_t d = j >> 3, x = j & 7u;
 #pragma unroll
-        for (int q = 0; q < CA; q++) cnt += s_a[((x << 8) | d) * CA + q];
+            for (int q = 0; q < CA; q++) cnt += s_a[((x << 8) | d) * CA + q];
+        } else {        // the joint field as it lies
+            cnt = s_a[j];
+        }
         if (cnt) atomicAdd(&field_a[j], cnt);
     }
     for (uint32_t j = tid; j < NB; j += T) {
@@ -222,38 +230,51 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
     }
 }
 
-hipError_t launch_hybrid_histograms(const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field_a, uint32_t* bucket,
+hipError_t launch_hybrid_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field_a, uint32_t* bucket,
                                     int bucket_bits, const uint32_t* skip, hipStream_t stream)
 {
-    if (bucket_bits < 11 || (1 << bucket_bits) > kHybridBuckets) return hipErrorInvalidValue;
+    if (bucket_bits < 11 || (1 << bucket_bits) > kHybridBuckets || (radix_bits != 8 && radix_bits != 4)) return hipErrorInvalidValue;
     constexpr int T = kHybridHistThreads;
-    constexpr size_t lds_bytes = (size_t)(2048 * kHybridCopiesA + kHybridBuckets) * sizeof(uint32_t);
+    constexpr size_t lds_bytes = (size_t)(4096 + kHybridBuckets) * sizeof(uint32_t);
+    static_assert(2048 * kHybridCopiesA == 4096, "both digit widths keep 4096 field counters");
     static_assert(lds_bytes <= 160 * 1024, "one workgroup per CU");
     if (region0_keys == 0 || region0_keys % (T * 4) != 0) return hipErrorInvalidValue;
-    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_histograms_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (attr != hipSuccess) return attr;
+    static hipError_t attr8 = hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_histograms_kernel<8>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    static hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_histograms_kernel<4>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (attr8 != hipSuccess) return attr8;
+    if (attr4 != hipSuccess) return attr4;
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const uint32_t vec_chunks = aligned ? n / (T * 4) : 0;
     // one resident workgroup per CU, each flushing 34816 counters once: more workgroups would only flush more
     uint32_t blocks = aligned ? (vec_chunks + kHybridVpt - 1) / kHybridVpt : (n + T * 16 - 1) / (T * 16);
     if (blocks > 256) blocks = 256;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(hybrid_histograms_kernel, dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks, skip, 32u - (uint32_t)bucket_bits);
+    if (radix_bits == 8)
+        hipLaunchKernelGGL(hybrid_histograms_kernel<8>, dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks, skip, 32u - (uint32_t)bucket_bits);
+    else
+        hipLaunchKernelGGL(hybrid_histograms_kernel<4>, dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks, skip, 32u - (uint32_t)bucket_bits);
     return hipGetLastError();
 }
 
 // The planner: one workgroup.  From the bucket counts: the verdict (largest bucket <= kLocalSortCap and the counts sum to n),
-// the buckets' bases (exclusive scan, kHybridBuckets + 1 words), the second global pass's (digit, region) counts -- region =
-// top three bits of the first pass's digit, i.e. sixteen consecutive buckets per cell -- and the plan words the other kernels read.
-template <int PER>   // consecutive buckets per thread = two (digit, region) cells: 32 for 2^15 buckets, 16 for 2^14
+// the buckets' bases (exclusive scan, 2^bucket_bits + 1 words), the plan words the other kernels read, and the global passes'
+// (digit, region) count fields that the upfront read has not written itself:
+//   8-bit digits: the second pass's field B -- region = top three bits of the first pass's digit, i.e. PER / 2 consecutive buckets
+//                 per cell;
+//   4-bit digits: all four ([pass][digit][region], region = the previous pass's digit): D (bits 28-31 by 24-27) and C (bits 24-27
+//                 by 20-23) are sums of buckets, B (bits 20-23 by 16-19) and A (bits 16-19 by position region) sums of the joint
+//                 field [position region][bits 16-23] of the upfront read.
+template <int R, int PER>   // PER = consecutive buckets per thread: 32 for 2^15 buckets, 16 for 2^14 (a thread = the top ten bits)
 __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __restrict__ bucket, uint32_t n, uint32_t* __restrict__ bases,
-                                                           uint32_t* __restrict__ field_b, uint32_t* __restrict__ words,
-                                                           uint32_t* __restrict__ large_list, uint32_t small_cap)
+                                                           uint32_t* __restrict__ fields_out, const uint32_t* __restrict__ joint,
+                                                           uint32_t* __restrict__ words, uint32_t* __restrict__ large_list, uint32_t small_cap)
 {
-    __shared__ uint32_t s_wave[16], s_max[16], s_large;
+    __shared__ uint32_t s_wave[16], s_max[16], s_large, s_c[256], s_d[256];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) s_large = 0;
+    if (R == 4 && tid < 256) s_c[tid] = s_d[tid] = 0;
     __syncthreads();
     uint32_t cnt[PER];
     const uint4* src = reinterpret_cast<const uint4*>(bucket + (size_t)tid * PER);
@@ -263,17 +284,40 @@ __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __res
         cnt[4 * j] = t.x; cnt[4 * j + 1] = t.y; cnt[4 * j + 2] = t.z; cnt[4 * j + 3] = t.w;
     }
     uint32_t sum = 0, mx = 0, half0 = 0;
+    uint32_t quarter[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < (int)PER; j++) {
         if (j == (int)PER / 2) half0 = sum;
         sum += cnt[j];
+        quarter[j / (PER / 4)] += cnt[j];
         mx = cnt[j] > mx ? cnt[j] : mx;
-        // the local stage's small variant (three workgroups per CU) takes buckets up to kLocalSortCapSmall keys; the others
+        // the launch over all buckets takes those of up to small_cap keys (the three-per-CU variant's capacity); the others
         // go on a list that a second, small launch walks with the large variant
         if (cnt[j] > small_cap) large_list[atomicAdd(&s_large, 1u)] = tid * PER + (uint32_t)j;
     }
-    field_b[2 * tid] = half0;             // cell (digit, region) = buckets [32 t, 32 t + 16): the layout of a pass's count table
-    field_b[2 * tid + 1] = sum - half0;
+    if (R == 8) {
+        fields_out[2 * tid] = half0;             // cell (digit, region) = buckets [PER t, PER t + PER / 2): the layout of a pass's count table
+        fields_out[2 * tid + 1] = sum - half0;
+    } else {
+        // tid = bits 22-31 of the key, a thread's quarter q = bits 20-21: cell D = [bits 28-31][bits 24-27] = tid >> 2,
+        // cell C = [bits 24-27][bits 20-23] = (tid & 63) << 2 | q
+        atomicAdd(&s_d[tid >> 2], sum);
+#pragma unroll
+        for (int q = 0; q < 4; q++) atomicAdd(&s_c[((tid & 63u) << 2) | (uint32_t)q], quarter[q]);
+        if (tid < 256) {          // A[digit d4][region x] = sum over d5 of joint[x][d5 << 4 | d4]
+            const uint32_t d4 = tid >> 4, x = tid & 15u;
+            uint32_t a = 0;
+#pragma unroll
+            for (uint32_t d5 = 0; d5 < 16; d5++) a += joint[x * 256u + ((d5 << 4) | d4)];
+            fields_out[tid] = a;
+        } else if (tid < 512) {   // B[digit d5][region d4] = sum over x of joint[x][d5 << 4 | d4]: index = bits 16-23 as they are
+            const uint32_t byte = tid - 256u;
+            uint32_t b = 0;
+#pragma unroll
+            for (uint32_t x = 0; x < 16; x++) b += joint[x * 256u + byte];
+            fields_out[256u + byte] = b;
+        }
+    }
     uint32_t incl = wave_inclusive_scan(sum, lane);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -283,6 +327,10 @@ __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __res
     if (lane == 63u) s_wave[wave] = incl;
     if (lane == 0u) s_max[wave] = mx;
     __syncthreads();
+    if (R == 4 && tid < 256) {
+        fields_out[512u + tid] = s_c[tid];
+        fields_out[768u + tid] = s_d[tid];
+    }
     uint32_t carry = 0, total = 0, largest = 0;
 #pragma unroll
     for (int w = 0; w < 16; w++) {
@@ -302,23 +350,28 @@ __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __res
         words[kHybridWordOk] = ok;            // the ordinary form's kernels return at once when this is set
         words[kHybridWordSkipLocal] = ok ^ 1u;
         words[kHybridWordLargeCount] = s_large;
-        words[kHybridWordPlanA] = ok ^ 1u;     // PassParams::plan of the first global pass: skip?, roles swapped?
-        words[kHybridWordPlanA + 1] = 0u;
-        words[kHybridWordPlanB] = ok ^ 1u;
-        words[kHybridWordPlanB + 1] = 1u;      // the second pass reads what the first one wrote
+#pragma unroll
+        for (int g = 0; g < 4; g++) {          // PassParams::plan of the g-th global pass: skip?, roles swapped?
+            words[kHybridWordPlan + 2 * g] = ok ^ 1u;
+            words[kHybridWordPlan + 2 * g + 1] = (uint32_t)(g & 1);   // an odd pass reads what the one before it wrote
+        }
         words[kHybridWordLargest] = largest;
     }
 }
 
-hipError_t launch_hybrid_plan(const uint32_t* bucket, uint32_t n, int bucket_bits, uint32_t* bases, uint32_t* field_b, uint32_t* words,
-                              uint32_t* large_list, uint32_t small_cap, hipStream_t stream)
+hipError_t launch_hybrid_plan(int radix_bits, const uint32_t* bucket, uint32_t n, int bucket_bits, uint32_t* bases, uint32_t* fields_out,
+                              const uint32_t* joint, uint32_t* words, uint32_t* large_list, uint32_t small_cap, hipStream_t stream)
 {
-    if (bucket_bits == 15)
-        hipLaunchKernelGGL(hybrid_plan_kernel<32>, dim3(1), dim3(1024), 0, stream, bucket, n, bases, field_b, words, large_list, small_cap);
-    else if (bucket_bits == 14)
-        hipLaunchKernelGGL(hybrid_plan_kernel<16>, dim3(1), dim3(1024), 0, stream, bucket, n, bases, field_b, words, large_list, small_cap);
-    else
+    if ((radix_bits != 8 && radix_bits != 4) || (radix_bits == 4 && !joint)) return hipErrorInvalidValue;
+#define LSD_PLAN(R, PER) hipLaunchKernelGGL((hybrid_plan_kernel<R, PER>), dim3(1), dim3(1024), 0, stream, bucket, n, bases, fields_out, joint, words, large_list, small_cap)
+    if (bucket_bits == 15) {
+        if (radix_bits == 8) LSD_PLAN(8, 32); else LSD_PLAN(4, 32);
+    } else if (bucket_bits == 14) {
+        if (radix_bits == 8) LSD_PLAN(8, 16); else LSD_PLAN(4, 16);
+    } else {
         return hipErrorInvalidValue;
+    }
+#undef LSD_PLAN
     return hipGetLastError();
 }
 

@@ -223,24 +223,33 @@ inline constexpr int hybrid_bucket_bits(size_t n) { return n >= ((size_t)1 << 27
 // plan words (uint32, in the workspace's control block): written by the planner, read by every kernel of either form
 constexpr int kHybridWordOk = 0;          // 1: the hybrid form runs (the ordinary form's kernels return at once)
 constexpr int kHybridWordSkipLocal = 1;   // 1: the local stage returns at once (both launches)
-constexpr int kHybridWordLargeCount = 7;  // buckets above the small variant's capacity: the entries of the planner's list
-constexpr int kHybridWordPlanA = 2;       // PassParams::plan of the first global pass (two words)
-constexpr int kHybridWordPlanB = 4;       // ... of the second
-constexpr int kHybridWordLargest = 6;     // the largest bucket (diagnostics)
-constexpr int kHybridWordHopeless = 8;    // 1: a sample of the keys already shows a bucket far above the capacity: the upfront read is skipped
-constexpr int kHybridWords = 9;
+constexpr int kHybridWordPlan = 2;        // PassParams::plan of the g-th global pass: words [2 + 2 g, 4 + 2 g), g < 4
+constexpr int kHybridWordLargest = 10;    // the largest bucket (diagnostics)
+constexpr int kHybridWordLargeCount = 11; // buckets above the small variant's capacity: the entries of the planner's list
+constexpr int kHybridWordHopeless = 12;   // 1: a sample of the keys already shows a bucket far above the capacity: the upfront read is skipped
+constexpr int kHybridWords = 13;
+// The global passes of the hybrid form cover bits 16-31: two at 8-bit digits, four at 4-bit digits.
+inline constexpr int hybrid_global_passes(int radix_bits) { return 16 / radix_bits; }
+// Count words of the form (zeroed with the workspace): the passes' [pass][digit][region] fields (8-bit: A from the upfront read,
+// B from the planner; 4-bit: all four from the planner), at 4-bit digits the upfront read's joint field [position region][bits
+// 16-23] the planner derives A and B from, then the buckets.
+inline constexpr size_t hybrid_field_words(int radix_bits) { return radix_bits == 8 ? 2 * 2048 : 4 * 256; }
+inline constexpr size_t hybrid_joint_words(int radix_bits) { return radix_bits == 8 ? 0 : 16 * 256; }
+inline constexpr size_t hybrid_count_words(int radix_bits) { return hybrid_field_words(radix_bits) + hybrid_joint_words(radix_bits) + kHybridBuckets; }
 // A look at 65536 keys taken at a regular stride: *hopeless = 1 if some bucket holds 0.8 % or more of a workgroup's 1024 samples
 // (its share is 0.003 %): such keys cannot take the hybrid form, and the 0.2-0.3 ms of its upfront read are saved (zeros, a default
 // value, small ranges, few-valued keys).
 hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bits, uint32_t* hopeless, hipStream_t stream);
-// field_a[(digit of bits 16-23) * 8 + position region] and bucket[key >> (32 - bucket_bits)] += counts (both zero on entry);
-// *skip != 0: nothing
-hipError_t launch_hybrid_histograms(const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field_a, uint32_t* bucket,
+// 8-bit digits: field[(digit of bits 16-23) * 8 + position region]; 4-bit digits: field[position region * 256 + bits 16-23] (the
+// joint field); and bucket[key >> (32 - bucket_bits)] += counts (all zero on entry).  *skip != 0: nothing
+hipError_t launch_hybrid_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field, uint32_t* bucket,
                                     int bucket_bits, const uint32_t* skip, hipStream_t stream);
-// verdict, bucket bases (2^bucket_bits + 1 words), the second pass's (digit, region) counts field_b[2048], plan words
+// verdict, bucket bases (2^bucket_bits + 1 words), plan words and the count fields the upfront read has not written: 8-bit digits
+// fields_out = the second pass's field B [256][8] (joint unused); 4-bit digits fields_out = all four passes' [4][16][16], from
+// joint and the buckets
 // ... and large_list[0 .. words[kHybridWordLargeCount]): the buckets of more than small_cap keys (up to 2^bucket_bits words)
-hipError_t launch_hybrid_plan(const uint32_t* bucket, uint32_t n, int bucket_bits, uint32_t* bases, uint32_t* field_b, uint32_t* words,
-                              uint32_t* large_list, uint32_t small_cap, hipStream_t stream);
+hipError_t launch_hybrid_plan(int radix_bits, const uint32_t* bucket, uint32_t n, int bucket_bits, uint32_t* bases, uint32_t* fields_out,
+                              const uint32_t* joint, uint32_t* words, uint32_t* large_list, uint32_t small_cap, hipStream_t stream);
 
 // counts64[b] = hist32[b], b < bins (multi-GPU bucket sizes as uint64).
 hipError_t launch_widen_counts(const uint32_t* hist32, uint64_t* counts64, int bins, hipStream_t stream);

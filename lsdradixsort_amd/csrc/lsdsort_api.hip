@@ -134,7 +134,7 @@ struct Layout {
     size_t alt_keys = 0;
     size_t alt_vals = 0;
     size_t alt_more[2] = {0, 0};   // further payload arrays (records: lsdsort_multi_u32_device)
-    size_t hyb_counts = 0;         // hybrid form (8-bit digits): field A [256][8] | field B [256][8] | buckets [32768], zeroed
+    size_t hyb_counts = 0;         // hybrid form: the global passes' count fields | (4-bit digits: the joint field) | buckets [32768], zeroed
     size_t hyb_bases = 0;          // [32769] bucket bases
     size_t total = 0;
     uint32_t tiles = 0;      // ceil(n / tile)
@@ -159,14 +159,15 @@ Layout make_layout(size_t n, int radix_bits, int payloads, int algorithm, const 
         L.regions = lsd::regions_for_radix(radix_bits);
         L.rows = L.tiles + (uint32_t)L.regions;          // one ragged last tile per region at most
         L.region0 = region0_keys(n, tile, L.regions);
-        const size_t hyb = radix_bits == 8 ? 2 : 0;   // the hybrid form's two global passes have ticket, count and table slots of their own
+        // the hybrid form's global passes (two at 8-bit digits, four at 4-bit) have ticket, count and table slots of their own
+        const size_t hyb = (radix_bits == 8 || radix_bits == 4) ? (size_t)lsd::hybrid_global_passes(radix_bits) : 0;
         L.tickets = off;
         off = align_up(off + (passes + hyb) * lsd::kMaxRegions * sizeof(uint32_t));
         L.counts = off;
         off = align_up(off + passes * bins * (size_t)L.regions * sizeof(uint32_t));
         if (hyb) {
             L.hyb_counts = off;
-            off = align_up(off + (2 * bins * (size_t)L.regions + lsd::kHybridBuckets) * sizeof(uint32_t));
+            off = align_up(off + lsd::hybrid_count_words(radix_bits) * sizeof(uint32_t));
         }
         L.status = off;
         off = align_up(off + (size_t)L.rows * bins * sizeof(uint32_t));
@@ -410,7 +411,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     // instead of 36.  Tried here for keys-only sorts of the sizes it pays for; the device decides from the exact bucket counts, and
     // every kernel of the form that does NOT run returns at once (plan words in the control block).
     uint32_t* hyb = nullptr;
-    if (plan && radix_bits == 8 && more == 0 && !feed && rank_method == lsd::kRankLdsAdd && n >= kHybridMinKeys && n <= kHybridMaxKeys &&
+    if (plan && (radix_bits == 8 || radix_bits == 4) && more == 0 && !feed && rank_method == lsd::kRankLdsAdd && n >= kHybridMinKeys && n <= kHybridMaxKeys &&
         (n >> lsd::hybrid_bucket_bits(n)) <= 14648 && shape->tile() == 32768 && g_hybrid.load(std::memory_order_relaxed))
         hyb = control + kHybridOffsetWords;
     if (timing) timing->hybrid = hyb ? -1 : 0;   // -1: tried; lsdsort_u32_device_timed reads the device's verdict back
@@ -418,20 +419,23 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
         uint32_t* counts = reinterpret_cast<uint32_t*>(ws + L.counts);
         tables = reinterpret_cast<uint32_t*>(ws + L.tables);
         if (hyb) {
-            uint32_t* field_a = reinterpret_cast<uint32_t*>(ws + L.hyb_counts);
-            uint32_t* field_b = field_a + 256 * L.regions;
-            uint32_t* bucket = field_b + 256 * L.regions;
+            // 8-bit digits: field A (upfront read) | field B (planner).  4-bit: fields A-D (planner) | the joint field (upfront read)
+            uint32_t* fields = reinterpret_cast<uint32_t*>(ws + L.hyb_counts);
+            uint32_t* joint = fields + lsd::hybrid_field_words(radix_bits);
+            uint32_t* bucket = joint + lsd::hybrid_joint_words(radix_bits);
             const int bb = lsd::hybrid_bucket_bits(n);
             LSD_HIP(lsd::launch_hybrid_sample(d_keys, (uint32_t)n, bb, hyb + lsd::kHybridWordHopeless, stream));
-            LSD_HIP(lsd::launch_hybrid_histograms(d_keys, (uint32_t)n, L.region0, field_a, bucket, bb, hyb + lsd::kHybridWordHopeless, stream));
+            LSD_HIP(lsd::launch_hybrid_histograms(radix_bits, d_keys, (uint32_t)n, L.region0, radix_bits == 8 ? fields : joint, bucket, bb,
+                                                  hyb + lsd::kHybridWordHopeless, stream));
             uint32_t* bases = reinterpret_cast<uint32_t*>(ws + L.hyb_bases);
-            LSD_HIP(lsd::launch_hybrid_plan(bucket, (uint32_t)n, bb, bases, field_b, hyb, bases + lsd::kHybridBuckets + 1,
+            LSD_HIP(lsd::launch_hybrid_plan(radix_bits, bucket, (uint32_t)n, bb, bases, radix_bits == 8 ? fields + 2048 : fields, joint, hyb,
+                                            bases + lsd::kHybridBuckets + 1,
                                             (uint32_t)(pairs ? lsd::kLocalSortCapSmallPairs : lsd::kLocalSortCapSmall), stream));
-            // the two global passes' region tables: pass A's regions are by position (like any first pass), pass B's by the top
-            // bits of A's digit -- exactly what stage 2 builds for two consecutive passes
+            // the global passes' region tables: the first one's regions are by position (like any first pass), the others' by the
+            // top bits of the digit before -- exactly what stage 2 builds for consecutive passes
             // (no fault word: where the sample or the planner has said no these counts are partial or absent, and nobody uses the tables)
-            LSD_HIP(lsd::launch_scan_regions(radix_bits, 2, L.regions, field_a, (uint32_t)n, (uint32_t)shape->tile(), L.region0,
-                                             tables + (size_t)passes * table_words, stream, nullptr, nullptr));
+            LSD_HIP(lsd::launch_scan_regions(radix_bits, lsd::hybrid_global_passes(radix_bits), L.regions, fields, (uint32_t)n,
+                                             (uint32_t)shape->tile(), L.region0, tables + (size_t)passes * table_words, stream, nullptr, nullptr));
         }
         // stage 1 over [first, first + len): the whole array at once, or chunk by chunk behind the host's copies
         auto histogram = [&](size_t first, size_t len) -> int {
@@ -477,8 +481,9 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
                                          L.region0, tables, stream, plan, control, hyb ? hyb + lsd::kHybridWordOk : nullptr));
         if (ev) LSD_TRY(ev->mark());
         if (hyb) {
-            // pass A: bits 16-23, caller's buffer -> alternate; pass B: bits 24-31, back; then the buckets in place
-            for (int g = 0; g < 2; g++) {
+            // bits 16-31, lowest digit first: caller's buffer -> alternate and back (an even number of passes); then the buckets in place
+            const int hyb_passes = lsd::hybrid_global_passes(radix_bits);
+            for (int g = 0; g < hyb_passes; g++) {
                 PassParams p{};
                 p.in = d_keys;
                 p.out = alt_keys;
@@ -486,15 +491,15 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
                 p.vals_out = alt_vals;
                 p.num_payloads = pairs ? 1u : 0u;
                 p.n = (uint32_t)n;
-                p.shift = (uint32_t)(16 + 8 * g);
+                p.shift = (uint32_t)(16 + radix_bits * g);
                 p.num_tiles = L.rows;
                 p.fault = control;
                 p.spin_limit = g_spin_limit.load(std::memory_order_relaxed);
                 p.regions = tables + (size_t)(passes + g) * table_words;
-                p.status = reinterpret_cast<uint32_t*>(ws + (g ? L.status_odd : L.status));
-                p.status_clear = g == 0 ? reinterpret_cast<uint32_t*>(ws + L.status_odd) : nullptr;
+                p.status = reinterpret_cast<uint32_t*>(ws + ((g & 1) ? L.status_odd : L.status));
+                p.status_clear = g + 1 < hyb_passes ? reinterpret_cast<uint32_t*>(ws + ((g & 1) ? L.status : L.status_odd)) : nullptr;
                 p.tickets = reinterpret_cast<uint32_t*>(ws + L.tickets) + (size_t)(passes + g) * lsd::kMaxRegions;
-                p.plan = hyb + (g ? lsd::kHybridWordPlanB : lsd::kHybridWordPlanA);
+                p.plan = hyb + lsd::kHybridWordPlan + 2 * g;
                 p.stats = g_stats.load(std::memory_order_relaxed);
                 if (ev) LSD_TRY(ev->arm_kernel_events());
                 const hipError_t launched = lsd::launch_rank_scatter(radix_bits, *shape, rank_method, true, p, stream);
@@ -1017,16 +1022,16 @@ int lsdsort_u32_device_timed(uint32_t* d_keys, uint32_t* d_vals, void* d_workspa
             LSD_HIP(hipEventElapsedTime(&out->scan_ms, ev.ev[2], ev.ev[3]));
             if (algorithm == LSDSORT_ALGO_ONESWEEP) {
                 // marks: 3 = before the first pass, the last = after the last; per pass: the kernel's own events.  Where the hybrid
-                // form was tried its two global passes come first (event pairs 0 and 1) and marks 4, 5 bracket the local stage.
+                // form was tried its global passes come first (event pairs 0, 1 and at 4-bit digits 2, 3) and marks 4, 5 bracket the local stage.
                 int first_pair = 0;
                 if (out->hybrid == -1) {
                     uint32_t ok = 0;
                     LSD_HIP(hipMemcpy(&ok, static_cast<const uint32_t*>(d_workspace) + kHybridOffsetWords + lsd::kHybridWordOk, sizeof(ok),
                                       hipMemcpyDeviceToHost));
                     out->hybrid = ok ? 1 : 0;
-                    first_pair = ok ? 0 : 2;
+                    first_pair = ok ? 0 : lsd::hybrid_global_passes(radix_bits);
                     if (ok) {
-                        out->passes = 2;
+                        out->passes = lsd::hybrid_global_passes(radix_bits);
                         if (ev.count >= 6) LSD_HIP(hipEventElapsedTime(&out->local_ms, ev.ev[4], ev.ev[5]));
                     }
                 }

@@ -58,8 +58,9 @@ def test_local_stage_alone(gpu):
                     assert np.array_equal(got_v[lo:hi], vals[lo:hi][order]), (low_bits, b, size, "payload order = stable order")
 
 
-@pytest.mark.parametrize("log2n,extra", [(26, 999), (27, 0), (27, 12345), (28, 777)])
-def test_hybrid_equals_torch_sort_and_the_four_pass_form(gpu, log2n, extra):
+@pytest.mark.parametrize("log2n,extra,radix", [(26, 999, 8), (27, 0, 8), (27, 12345, 8), (28, 777, 8), (26, 4097, 4), (27, 31, 4), (28, 5, 4)])
+def test_hybrid_equals_torch_sort_and_the_four_pass_form(gpu, log2n, extra, radix):
+    """radix 8: two global passes; radix 4 (BASELINE configs[1]'s digit width): four, their count fields derived by the planner."""
     import torch
 
     n = (1 << log2n) + extra
@@ -68,7 +69,7 @@ def test_hybrid_equals_torch_sort_and_the_four_pass_form(gpu, log2n, extra):
     gen = torch.Generator(device="cuda")
     gen.manual_seed(4000 + log2n + extra)
     base = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda", generator=gen)
-    ws = gpu.alloc_workspace(n, 8)
+    ws = gpu.alloc_workspace(n, radix)
     shapes = {
         "uniform": lambda: base.clone(),
         "sorted": lambda: _i32(torch.sort(_u64(base)).values),
@@ -87,14 +88,14 @@ def test_hybrid_equals_torch_sort_and_the_four_pass_form(gpu, log2n, extra):
         keys = make()
         expect = torch.sort(_u64(keys)).values
         d = keys.clone()
-        tm = gpu.GPULSDRadixSortTimed(d, 8, workspace=ws)
+        tm = gpu.GPULSDRadixSortTimed(d, radix, workspace=ws)
         taken[name] = tm["hybrid"]
         assert torch.equal(_u64(d), expect), (name, "hybrid on", tm["hybrid"])
         assert gpu.lib().lsdsort_check_device(ws.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0, name
         gpu.set_hybrid(False)
         try:
             d2 = keys.clone()
-            tm2 = gpu.GPULSDRadixSortTimed(d2, 8, workspace=ws)
+            tm2 = gpu.GPULSDRadixSortTimed(d2, radix, workspace=ws)
             assert tm2["hybrid"] == 0
             assert torch.equal(d2, d), (name, "the two forms differ")
         finally:
@@ -140,7 +141,7 @@ def test_hybrid_pairs_are_stable(gpu, n):
 
 
 def test_hybrid_is_not_tried_outside_its_range(gpu):
-    """Below 2^26 keys, at 4-bit digits, with more than one payload array and for typed keys the four-pass form runs."""
+    """Below 2^26 keys, at 1- and 2-bit digits, with more than one payload array and for typed keys the ordinary form runs."""
     import torch
 
     n = (1 << 26) - 5
@@ -150,5 +151,5 @@ def test_hybrid_is_not_tried_outside_its_range(gpu):
     assert tm["hybrid"] == 0 and torch.equal(_u64(d), expect)
     n = (1 << 27) + 3
     d = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda")
-    tm = gpu.GPULSDRadixSortTimed(d.clone(), 4)
+    tm = gpu.GPULSDRadixSortTimed(d.clone(), 2)
     assert tm["hybrid"] == 0
