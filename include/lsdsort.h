@@ -382,14 +382,19 @@ LSDSORT_API int lsdsort_set_xcd_chunk(int chunk);
  * sorts and 1-bit digits always run every pass.  0 switches it off (every pass runs, as the reference's do). */
 LSDSORT_API int lsdsort_set_pass_skipping(int on);
 /* The hybrid form (lsdradixsort_amd/csrc/hybrid.hip, local_sort.hip; no reference counterpart -- its every pass goes through
- * global memory, .cu:844-905).  Sorts of keys or key/value pairs with 8-bit digits of 2^27 .. 4.8e8 items: the two HIGH digits are sorted first
- * by two ordinary global passes (LSD order: bits 16-23, then 24-31), which leaves the array sorted by its top 16 bits; every
- * bucket of equal top-15-bit value (2^15 of them) is then finished inside one CU's LDS (bits 0-8, then 9-16) and stored once:
- * 4 + 8 + 8 + 8 = 28 bytes per key of memory traffic instead of 4 + 4 x 8 = 36 (pairs: 52 instead of 68).  Valid only if every bucket fits the local stage
- * (16384 keys), which depends on the keys: the upfront read counts the buckets exactly and the DEVICE decides before a key is
- * moved; otherwise the ordinary four global passes run (after their own upfront read: such keys pay about 10 % for the
- * attempt).  Same result either way.  On by default; 0 = always the four global passes, as the reference's structure. */
+ * global memory, .cu:844-905).  Sorts of 2^26 .. 4.8e8 keys or key/value pairs (uint32, int32, float32, either order) with 8- or
+ * 4-bit digits: bits 16-31 are sorted first by ordinary global passes (LSD order; two passes at 8-bit digits, four at 4-bit),
+ * which leaves the array sorted by its top 16 bits; every bucket of equal top-15-bit value (top 14 bits below 2^27 items) is
+ * then finished inside one CU's LDS (bits 0-8, then 9-16) and stored once: at 8-bit digits 4 + 8 + 8 + 8 = 28 bytes per key of
+ * memory traffic instead of 4 + 4 x 8 = 36 (pairs: 52 instead of 68), at 4-bit digits 44 instead of 68.  Valid only if every
+ * bucket fits the local stage (16384 keys), which depends on the keys: the upfront read counts the buckets exactly and the
+ * DEVICE decides before a key is moved; otherwise the ordinary passes run (after their own upfront read: such keys pay about
+ * 10 % for the attempt, 1 % where a 65536-key sample already shows it).  Same result either way.  On by default; 0 = always
+ * the ordinary passes, the reference's structure. */
 LSDSORT_API int lsdsort_set_hybrid(int on);
+/* Which form the last sort queued on `hip_stream` in this workspace ran: *hybrid = 1 the hybrid form, 0 the ordinary passes (also
+ * where the hybrid form was not tried).  Reads the device's verdict back: synchronises the stream. */
+LSDSORT_API int lsdsort_workspace_form(const void* d_workspace, void* hip_stream, int* hybrid);
 /* Runtime tuning knob for experiments: selects among the compiled tile shapes (see
  * DESIGN.md); -1 restores the default.  Returns LSDSORT_ERR_INVALID_ARG if unknown. */
 LSDSORT_API int lsdsort_set_tile_config(int radix_bits, int config_id);

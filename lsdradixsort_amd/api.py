@@ -120,6 +120,15 @@ def set_hybrid(on: bool) -> None:
     check(lib().lsdsort_set_hybrid(1 if on else 0), "lsdsort_set_hybrid")
 
 
+def workspace_form(workspace, stream=None) -> int:
+    """1 if the last sort queued in ``workspace`` ran the hybrid form, 0 if the ordinary passes (``lsdsort_workspace_form``)."""
+    import ctypes
+
+    out = ctypes.c_int(0)
+    check(lib().lsdsort_workspace_form(workspace.data_ptr(), _stream(stream), ctypes.byref(out)), "lsdsort_workspace_form")
+    return out.value
+
+
 def set_pass_skipping(on: bool) -> None:
     """Skip passes whose digit is the same for every key (decided on the device from the digit counts; default on)."""
     check(lib().lsdsort_set_pass_skipping(1 if on else 0), "lsdsort_set_pass_skipping")

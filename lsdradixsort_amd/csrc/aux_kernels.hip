@@ -710,7 +710,7 @@ __global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __res
                                                           uint32_t tile_keys, uint32_t region0_keys, int passes,
                                                           uint32_t* __restrict__ tables, uint32_t table_words,
                                                           uint32_t* __restrict__ plan, uint32_t* __restrict__ fault,
-                                                          const uint32_t* __restrict__ hybrid_ok)
+                                                          const uint32_t* __restrict__ hybrid_ok, uint32_t skip_dead_passes)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base[257];
@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(256) scan_regions_kernel(const uint32_t* __res
             uint32_t t = 0;
 #pragma unroll
             for (int x = 0; x < REG; x++) t += counts[(size_t)cell * REG + x];
-            if (t == n) s_const[cell / (uint32_t)bins] = 1;
+            if (t == n && skip_dead_passes) s_const[cell / (uint32_t)bins] = 1;
         }
         __syncthreads();
         if (tid == 0) {
@@ -842,24 +842,25 @@ hipError_t launch_finish_plan(const uint32_t* plan_final, uint32_t* keys, const 
 
 hipError_t launch_scan_regions(int radix_bits, int passes, int regions, const uint32_t* counts, uint32_t n,
                                uint32_t tile_keys, uint32_t region0_keys, uint32_t* tables, hipStream_t stream, uint32_t* plan,
-                               uint32_t* fault, const uint32_t* hybrid_ok)
+                               uint32_t* fault, const uint32_t* hybrid_ok, bool skip_dead_passes)
 {
     if (radix_bits < 1 || radix_bits > 8 || (regions != 1 && regions != regions_for_radix(radix_bits))) return hipErrorInvalidValue;
+    const uint32_t sdp = skip_dead_passes ? 1u : 0u;
     if (plan && 2 * passes + 1 > kPlanWords) return hipErrorInvalidValue;
     const int bins = 1 << radix_bits;
     const uint32_t words = (uint32_t)region_table_words(radix_bits);
     if (regions == 1)
         hipLaunchKernelGGL((scan_regions_kernel<1>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
-                           region0_keys, passes, tables, words, plan, fault, hybrid_ok);
+                           region0_keys, passes, tables, words, plan, fault, hybrid_ok, sdp);
     else if (regions == 8)
         hipLaunchKernelGGL((scan_regions_kernel<8>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
-                           region0_keys, passes, tables, words, plan, fault, hybrid_ok);
+                           region0_keys, passes, tables, words, plan, fault, hybrid_ok, sdp);
     else if (regions == 16)
         hipLaunchKernelGGL((scan_regions_kernel<16>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
-                           region0_keys, passes, tables, words, plan, fault, hybrid_ok);
+                           region0_keys, passes, tables, words, plan, fault, hybrid_ok, sdp);
     else
         hipLaunchKernelGGL((scan_regions_kernel<32>), dim3(passes), dim3(256), 0, stream, counts, bins, n, tile_keys,
-                           region0_keys, passes, tables, words, plan, fault, hybrid_ok);
+                           region0_keys, passes, tables, words, plan, fault, hybrid_ok, sdp);
     return hipGetLastError();
 }
 

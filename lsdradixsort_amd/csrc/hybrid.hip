@@ -61,11 +61,12 @@ hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bit
     return hipGetLastError();
 }
 
-template <int R>   // digit width of the global passes: 8 or 4
+template <int R, bool XF>   // R: digit width of the global passes, 8 or 4.  XF: typed keys, counted as to_sortable(key, xf)
 __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                                uint32_t region0_keys, uint32_t* __restrict__ field_a,
                                                                                uint32_t* __restrict__ bucket, uint32_t vec_chunks,
-                                                                               const uint32_t* __restrict__ skip, uint32_t bucket_shift)
+                                                                               const uint32_t* __restrict__ skip, uint32_t bucket_shift,
+                                                                               const KeyTransform xf)
 {
     if (skip && *skip != 0u) return;   // uniform: the sample has ruled the hybrid form out (the planner then sees no counts: not ok)
     // 8-bit digits: the first pass's field, [8 position regions][256 digits], two lane-class copies.  4-bit digits: the JOINT field
@@ -186,7 +187,8 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
 #pragma unroll
         for (int u = 0; u < VPT; u++) {
             const u32x4 t = __builtin_nontemporal_load(k4p + (size_t)(c + u) * T + tid);
-            v[u] = make_uint4(t.x, t.y, t.z, t.w);
+            v[u] = XF ? make_uint4(to_sortable(t.x, xf), to_sortable(t.y, xf), to_sortable(t.z, xf), to_sortable(t.w, xf))
+                      : make_uint4(t.x, t.y, t.z, t.w);
         }
     };
     const uint32_t full_chunks = vec_chunks / VPT * VPT;
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
     }
     // tail (and everything, for a base that is not 16-byte aligned: vec_chunks == 0): one key per thread per step
     for (size_t i = (size_t)full_chunks * (T * 4) + (size_t)blockIdx.x * T + tid; i < n; i += (size_t)gridDim.x * T)
-        count_plain(keys[i], (uint32_t)(i / region0_keys));
+        count_plain(XF ? to_sortable(keys[i], xf) : keys[i], (uint32_t)(i / region0_keys));
     __syncthreads();
     for (uint32_t j = tid; j < FA; j += T) {
         uint32_t cnt = 0;
@@ -231,7 +233,7 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
 }
 
 hipError_t launch_hybrid_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field_a, uint32_t* bucket,
-                                    int bucket_bits, const uint32_t* skip, hipStream_t stream)
+                                    int bucket_bits, const uint32_t* skip, hipStream_t stream, const KeyTransform& xf)
 {
     if (bucket_bits < 11 || (1 << bucket_bits) > kHybridBuckets || (radix_bits != 8 && radix_bits != 4)) return hipErrorInvalidValue;
     constexpr int T = kHybridHistThreads;
@@ -239,22 +241,29 @@ hipError_t launch_hybrid_histograms(int radix_bits, const uint32_t* keys, uint32
     static_assert(2048 * kHybridCopiesA == 4096, "both digit widths keep 4096 field counters");
     static_assert(lds_bytes <= 160 * 1024, "one workgroup per CU");
     if (region0_keys == 0 || region0_keys % (T * 4) != 0) return hipErrorInvalidValue;
-    static hipError_t attr8 = hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_histograms_kernel<8>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    static hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_histograms_kernel<4>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (attr8 != hipSuccess) return attr8;
-    if (attr4 != hipSuccess) return attr4;
+    static hipError_t attr = [] {
+        const void* kernels[4] = {reinterpret_cast<const void*>(hybrid_histograms_kernel<8, false>), reinterpret_cast<const void*>(hybrid_histograms_kernel<8, true>),
+                                  reinterpret_cast<const void*>(hybrid_histograms_kernel<4, false>), reinterpret_cast<const void*>(hybrid_histograms_kernel<4, true>)};
+        for (const void* k : kernels) {
+            const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }();
+    if (attr != hipSuccess) return attr;
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const uint32_t vec_chunks = aligned ? n / (T * 4) : 0;
     // one resident workgroup per CU, each flushing 34816 counters once: more workgroups would only flush more
     uint32_t blocks = aligned ? (vec_chunks + kHybridVpt - 1) / kHybridVpt : (n + T * 16 - 1) / (T * 16);
     if (blocks > 256) blocks = 256;
     if (blocks == 0) blocks = 1;
-    if (radix_bits == 8)
-        hipLaunchKernelGGL(hybrid_histograms_kernel<8>, dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks, skip, 32u - (uint32_t)bucket_bits);
-    else
-        hipLaunchKernelGGL(hybrid_histograms_kernel<4>, dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks, skip, 32u - (uint32_t)bucket_bits);
+#define LSD_HYB_HIST(R, XF) hipLaunchKernelGGL((hybrid_histograms_kernel<R, XF>), dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks, skip, 32u - (uint32_t)bucket_bits, xf)
+    if (radix_bits == 8) {
+        if (xf.on) LSD_HYB_HIST(8, true); else LSD_HYB_HIST(8, false);
+    } else {
+        if (xf.on) LSD_HYB_HIST(4, true); else LSD_HYB_HIST(4, false);
+    }
+#undef LSD_HYB_HIST
     return hipGetLastError();
 }
 

@@ -38,7 +38,7 @@ constexpr size_t local_lds_words() { return (size_t)kLocalThreads * K + kLocalWa
 // of the other launch); uniform keys at 2^28 have buckets of 8192 +- 300.
 // PAIRS: a payload word follows each key (LocalSortParams::vals).  It takes the key's LDS slot in a second round of every pass, as
 // in the global pass kernel: keys to LDS, keys back, payloads to the same slots, payloads back -- two more barriers per pass.
-template <int K, bool PAIRS>
+template <int K, bool PAIRS, bool XOUT>
 __device__ __forceinline__ void sort_bucket(const LocalSortParams& p, const uint32_t b)
 {
     constexpr int T = kLocalThreads, W = kLocalWaves, HW = kLocalMaxBins / 2;   // HW: counter words per wave
@@ -132,7 +132,9 @@ __device__ __forceinline__ void sort_bucket(const LocalSortParams& p, const uint
     // payloads: the same for them, through the same slots, once the keys have been taken out.
     auto take_out = [&](bool last) {
         if (last) {
-            for (uint32_t q = tid; q < size; q += (uint32_t)T) bucket[q] = s_keys[q];
+            // XOUT: a typed sort's keys leave as what they were (int32, float32, descending order).  A kernel of its own: the
+            // five instructions per key cost the uint32 sort 0.025 ms of 0.59 when they sat in the one store loop
+            for (uint32_t q = tid; q < size; q += (uint32_t)T) bucket[q] = XOUT ? from_sortable(s_keys[q], p.xout) : s_keys[q];
         } else {
 #pragma unroll
             for (int i = 0; i < K; i++)
@@ -172,33 +174,40 @@ template <int K, bool PAIRS>
 constexpr int local_waves_per_simd() { return (PAIRS ? K <= 16 : K <= 20) ? 6 : (PAIRS ? 2 : 4); }
 
 // one bucket per workgroup
-template <int K, bool PAIRS>
+template <int K, bool PAIRS, bool XOUT>
 __global__ void __launch_bounds__(kLocalThreads, (local_waves_per_simd<K, PAIRS>())) local_sort_kernel(const LocalSortParams p)
 {
     if (p.skip && *p.skip != 0u) return;   // uniform: the plan took the other form
-    sort_bucket<K, PAIRS>(p, blockIdx.x);
+    sort_bucket<K, PAIRS, XOUT>(p, blockIdx.x);
 }
 
 // The buckets of the planner's list (those above the small variant's capacity), dealt over a small grid: uniform keys leave
 // the list empty, and a launch of 32768 workgroups that each find nothing to do costs 17 us.
-template <int K, bool PAIRS>
+template <int K, bool PAIRS, bool XOUT>
 __global__ void __launch_bounds__(kLocalThreads, (local_waves_per_simd<K, PAIRS>())) local_sort_list_kernel(const LocalSortParams p)
 {
     if (p.skip && *p.skip != 0u) return;
     const uint32_t listed = *p.list_count;
     for (uint32_t item = blockIdx.x; item < listed; item += gridDim.x) {
-        sort_bucket<K, PAIRS>(p, p.list[item]);
+        sort_bucket<K, PAIRS, XOUT>(p, p.list[item]);
         __syncthreads();   // the next bucket reuses the LDS
     }
 }
 
+template <int K, bool PAIRS, bool XOUT>
+static hipError_t launch_local_inst_x(const LocalSortParams& p, hipStream_t stream);
 template <int K, bool PAIRS>
 static hipError_t launch_local_inst(const LocalSortParams& p, hipStream_t stream)
+{
+    return p.xout.on ? launch_local_inst_x<K, PAIRS, true>(p, stream) : launch_local_inst_x<K, PAIRS, false>(p, stream);
+}
+template <int K, bool PAIRS, bool XOUT>
+static hipError_t launch_local_inst_x(const LocalSortParams& p, hipStream_t stream)
 {
     constexpr size_t lds_bytes = local_lds_words<K>() * sizeof(uint32_t);
     if (p.list) {
         if constexpr (K == 32) {   // the list is the large variant's
-            auto kernel = local_sort_list_kernel<K, PAIRS>;
+            auto kernel = local_sort_list_kernel<K, PAIRS, XOUT>;
             static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (attr != hipSuccess) return attr;
             hipLaunchKernelGGL(kernel, dim3(512), dim3(kLocalThreads), lds_bytes, stream, p);   // two workgroups per CU walk the list
@@ -206,7 +215,7 @@ static hipError_t launch_local_inst(const LocalSortParams& p, hipStream_t stream
         }
         return hipErrorInvalidValue;
     }
-    auto kernel = local_sort_kernel<K, PAIRS>;
+    auto kernel = local_sort_kernel<K, PAIRS, XOUT>;
     if (lds_bytes > 64 * 1024) {
         static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (attr != hipSuccess) return attr;

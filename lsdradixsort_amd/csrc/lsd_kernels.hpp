@@ -173,9 +173,12 @@ hipError_t launch_joint_histograms(int radix_bits, const uint32_t* keys, uint32_
 // `fault` (may be null): the workspace fault word, raised (bit 2) if a pass's counts do not sum to n.
 // `hybrid_ok` (may be null): *hybrid_ok != 0 = the hybrid form runs instead: the plan then says "skip, and leave the status rows
 // alone" (2) for every pass and nothing else is written.
+// `skip_dead_passes` = false: the plan never marks a pass as the identity (typed sorts: their first and last pass carry the key
+// transform), it only says which way round each pass runs.
 hipError_t launch_scan_regions(int radix_bits, int passes, int regions, const uint32_t* counts, uint32_t n,
                                uint32_t tile_keys, uint32_t region0_keys, uint32_t* tables, hipStream_t stream,
-                               uint32_t* plan = nullptr, uint32_t* fault = nullptr, const uint32_t* hybrid_ok = nullptr);
+                               uint32_t* plan = nullptr, uint32_t* fault = nullptr, const uint32_t* hybrid_ok = nullptr,
+                               bool skip_dead_passes = true);
 // The pass plan stage 2 writes when asked to (PassParams::plan): 2 words per pass, then plan[2 * passes] != 0 if the sorted
 // keys ended up in the second buffer.  launch_finish_plan copies them (and the payloads) back in that case.
 constexpr int kPlanWords = 2 * 16 + 1;   // up to 16 passes (2-bit digits)
@@ -210,6 +213,7 @@ struct LocalSortParams {
     uint32_t* fault;
     uint32_t small_variant;   // 1: buckets of up to kLocalSortCapSmall keys, three workgroups per CU
     uint32_t larger_elsewhere;   // 1: a bucket above this launch's capacity is another launch's (no fault)
+    KeyTransform xout;           // typed sorts: the stage's store turns the sortable keys back (from_sortable)
     const uint32_t* list;        // null: bucket = workgroup index.  Else the buckets to sort, *list_count of them, walked by a
     const uint32_t* list_count;  // grid of 512 workgroups
 };
@@ -242,8 +246,9 @@ inline constexpr size_t hybrid_count_words(int radix_bits) { return hybrid_field
 hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bits, uint32_t* hopeless, hipStream_t stream);
 // 8-bit digits: field[(digit of bits 16-23) * 8 + position region]; 4-bit digits: field[position region * 256 + bits 16-23] (the
 // joint field); and bucket[key >> (32 - bucket_bits)] += counts (all zero on entry).  *skip != 0: nothing
+// xf: the keys are counted as to_sortable(key, xf) (typed sorts: what the first global pass will store)
 hipError_t launch_hybrid_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field, uint32_t* bucket,
-                                    int bucket_bits, const uint32_t* skip, hipStream_t stream);
+                                    int bucket_bits, const uint32_t* skip, hipStream_t stream, const KeyTransform& xf = KeyTransform{});
 // verdict, bucket bases (2^bucket_bits + 1 words), plan words and the count fields the upfront read has not written: 8-bit digits
 // fields_out = the second pass's field B [256][8] (joint unused); 4-bit digits fields_out = all four passes' [4][16][16], from
 // joint and the buckets

@@ -404,16 +404,20 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     // pass kernels follow (lsd_kernels.hpp, PassParams::plan) -- small key ranges, dead digits and constant input then cost
     // the passes that move something, plus one copy if their number is odd.  Not for typed sorts (their first and last
     // pass carry the key transform) nor where the plan would not fit the control block.
+    // A typed sort gets a plan only where the hybrid form is tried (its kernels are told by the plan which form runs), and that plan
+    // never skips a pass.
+    const bool try_hybrid = algorithm == LSDSORT_ALGO_ONESWEEP && (radix_bits == 8 || radix_bits == 4) && more == 0 && !feed &&
+                            rank_method == lsd::kRankLdsAdd && n >= kHybridMinKeys && n <= kHybridMaxKeys &&
+                            (n >> lsd::hybrid_bucket_bits(n)) <= 14648 && shape->tile() == 32768 && g_hybrid.load(std::memory_order_relaxed);
     uint32_t* plan = nullptr;
-    if (algorithm == LSDSORT_ALGO_ONESWEEP && !xf.on && 2 * passes + 1 <= lsd::kPlanWords && g_skip_dead_passes.load(std::memory_order_relaxed))
+    if (algorithm == LSDSORT_ALGO_ONESWEEP && (!xf.on || try_hybrid) && 2 * passes + 1 <= lsd::kPlanWords &&
+        g_skip_dead_passes.load(std::memory_order_relaxed))
         plan = control + kPlanOffsetWords;
     // The hybrid form (hybrid.hip): two global passes on the high bytes, then every top-15-bit bucket finished in LDS -- 28 B/key
     // instead of 36.  Tried here for keys-only sorts of the sizes it pays for; the device decides from the exact bucket counts, and
     // every kernel of the form that does NOT run returns at once (plan words in the control block).
     uint32_t* hyb = nullptr;
-    if (plan && (radix_bits == 8 || radix_bits == 4) && more == 0 && !feed && rank_method == lsd::kRankLdsAdd && n >= kHybridMinKeys && n <= kHybridMaxKeys &&
-        (n >> lsd::hybrid_bucket_bits(n)) <= 14648 && shape->tile() == 32768 && g_hybrid.load(std::memory_order_relaxed))
-        hyb = control + kHybridOffsetWords;
+    if (plan && try_hybrid) hyb = control + kHybridOffsetWords;
     if (timing) timing->hybrid = hyb ? -1 : 0;   // -1: tried; lsdsort_u32_device_timed reads the device's verdict back
     if (algorithm == LSDSORT_ALGO_ONESWEEP) {
         uint32_t* counts = reinterpret_cast<uint32_t*>(ws + L.counts);
@@ -426,7 +430,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             const int bb = lsd::hybrid_bucket_bits(n);
             LSD_HIP(lsd::launch_hybrid_sample(d_keys, (uint32_t)n, bb, hyb + lsd::kHybridWordHopeless, stream));
             LSD_HIP(lsd::launch_hybrid_histograms(radix_bits, d_keys, (uint32_t)n, L.region0, radix_bits == 8 ? fields : joint, bucket, bb,
-                                                  hyb + lsd::kHybridWordHopeless, stream));
+                                                  hyb + lsd::kHybridWordHopeless, stream, xf));
             uint32_t* bases = reinterpret_cast<uint32_t*>(ws + L.hyb_bases);
             LSD_HIP(lsd::launch_hybrid_plan(radix_bits, bucket, (uint32_t)n, bb, bases, radix_bits == 8 ? fields + 2048 : fields, joint, hyb,
                                             bases + lsd::kHybridBuckets + 1,
@@ -478,7 +482,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
         }
 #endif
         LSD_HIP(lsd::launch_scan_regions(radix_bits, passes, L.regions, counts, (uint32_t)n, (uint32_t)shape->tile(),
-                                         L.region0, tables, stream, plan, control, hyb ? hyb + lsd::kHybridWordOk : nullptr));
+                                         L.region0, tables, stream, plan, control, hyb ? hyb + lsd::kHybridWordOk : nullptr, !xf.on));
         if (ev) LSD_TRY(ev->mark());
         if (hyb) {
             // bits 16-31, lowest digit first: caller's buffer -> alternate and back (an even number of passes); then the buckets in place
@@ -500,6 +504,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
                 p.status_clear = g + 1 < hyb_passes ? reinterpret_cast<uint32_t*>(ws + ((g & 1) ? L.status : L.status_odd)) : nullptr;
                 p.tickets = reinterpret_cast<uint32_t*>(ws + L.tickets) + (size_t)(passes + g) * lsd::kMaxRegions;
                 p.plan = hyb + lsd::kHybridWordPlan + 2 * g;
+                if (xf.on && g == 0) p.xin = xf;   // typed sorts: sortable keys from the first store on; the local stage's store turns them back
                 p.stats = g_stats.load(std::memory_order_relaxed);
                 if (ev) LSD_TRY(ev->arm_kernel_events());
                 const hipError_t launched = lsd::launch_rank_scatter(radix_bits, *shape, rank_method, true, p, stream);
@@ -515,6 +520,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             lp.shift[0] = 0; lp.width[0] = 9;      // bits 0-8, then 9-16 (or 9-17): the 17 (18) bits below a bucket's own
             lp.shift[1] = 9; lp.width[1] = (uint32_t)(32 - bb - 9);
             lp.skip = hyb + lsd::kHybridWordSkipLocal;
+            lp.xout = xf;
             lp.fault = control;
             if (ev) LSD_TRY(ev->mark());
             lp.small_variant = 1;     // buckets of up to 10240 keys (all of them on uniform keys of these sizes): three workgroups per CU
@@ -795,6 +801,18 @@ int lsdsort_set_xcd_chunk(int chunk)
 {
     if (chunk < 0 || chunk > (int)kMaxXcdChunk) return LSDSORT_ERR_INVALID_ARG;
     g_xcd_chunk.store((uint32_t)chunk, std::memory_order_relaxed);
+    return LSDSORT_OK;
+}
+
+int lsdsort_workspace_form(const void* d_workspace, void* hip_stream, int* hybrid)
+{
+    if (!d_workspace || !hybrid) return LSDSORT_ERR_INVALID_ARG;
+    // the opening memset of every sort clears the word; only the hybrid planner sets it
+    uint32_t ok = 0;
+    LSD_HIP(hipMemcpyAsync(&ok, static_cast<const uint32_t*>(d_workspace) + kHybridOffsetWords + lsd::kHybridWordOk, sizeof(ok),
+                           hipMemcpyDeviceToHost, static_cast<hipStream_t>(hip_stream)));
+    LSD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));
+    *hybrid = ok ? 1 : 0;
     return LSDSORT_OK;
 }
 

@@ -153,3 +153,63 @@ def test_hybrid_is_not_tried_outside_its_range(gpu):
     d = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda")
     tm = gpu.GPULSDRadixSortTimed(d.clone(), 2)
     assert tm["hybrid"] == 0
+
+
+@pytest.mark.parametrize("key_type,descending,radix,log2n", [("int32", False, 8, 27), ("float32", False, 8, 26), ("float32", True, 8, 27),
+                                                             ("uint32", True, 4, 26), ("int32", True, 4, 27)])
+def test_typed_keys_take_the_hybrid_form(gpu, key_type, descending, radix, log2n):
+    """int32 / float32 / descending sorts of hybrid sizes (lsdsort_keys_device): the upfront read counts the sortable form of the
+    keys, the first global pass stores it, the local stage's store turns it back.  Against torch.sort of the typed tensor
+    (float32: random bit patterns with the NaNs replaced; -0 < +0 by IEEE total order is checked on the bits); the form that ran
+    is read from the workspace; with pairs, the payload order is torch's stable order."""
+    import torch
+
+    n = (1 << log2n) + 1234
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(99 + log2n + radix)
+    bits = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda", generator=gen)
+    if key_type == "float32":
+        # NaN / inf patterns (exponent 0xFF, 0.4 % of random bits) become finite values of their own: one replacement value for
+        # all of them would be a bucket of 2^18 equal keys, which the planner rightly refuses
+        bad = ((bits >> 23) & 0xFF) == 0xFF
+        bits = torch.where(bad, bits & ~(1 << 30), bits)
+        keys = bits.view(torch.float32).clone()
+        keys[:4] = torch.tensor([0.0, -0.0, float("inf"), float("-inf")], device="cuda")
+    else:
+        keys = bits.clone()
+    for pairs in (False, True):
+        d = keys.clone()
+        v = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
+        ws = gpu.alloc_workspace(n, radix, pairs)
+        gpu.GPUSortTyped(d, key_type, descending, d_vals=v, r=radix, workspace=ws, check_fault=True)
+        assert gpu.workspace_form(ws) == 1, (key_type, descending, radix, pairs)
+        if key_type == "uint32":
+            ref = _u64(keys)
+            got = _u64(d)
+        else:
+            ref, got = keys, d
+        expect = torch.sort(ref, descending=descending, stable=True)
+        if key_type == "float32":
+            # torch's sort treats -0 == +0; compare values, then the bit order of the zeros separately
+            assert torch.equal(got, expect.values)
+            zeros = got[got == 0].view(torch.int32)
+            if zeros.numel() > 1:
+                neg_first = bool((zeros[:-1] <= zeros[1:]).all()) if not descending else bool((zeros[:-1] >= zeros[1:]).all())
+                # ascending: -0 (0x80000000 = int32 min) before +0 (0); descending: +0 before -0
+                assert neg_first
+        else:
+            assert torch.equal(got, expect.values), (key_type, descending, radix, pairs)
+        if pairs and key_type != "float32":
+            assert torch.equal(v.to(torch.int64), expect.indices), "payloads keep the input order among equal keys"
+        # the ordinary passes give the same
+        gpu.set_hybrid(False)
+        try:
+            d2 = keys.clone()
+            v2 = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
+            gpu.GPUSortTyped(d2, key_type, descending, d_vals=v2, r=radix, workspace=ws, check_fault=True)
+            assert gpu.workspace_form(ws) == 0
+            assert torch.equal(d2.view(torch.int32), d.view(torch.int32))
+            if pairs:
+                assert torch.equal(v2, v)
+        finally:
+            gpu.set_hybrid(True)
