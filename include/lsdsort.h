@@ -395,6 +395,14 @@ LSDSORT_API int lsdsort_set_hybrid(int on);
 /* Which form the last sort queued on `hip_stream` in this workspace ran: *hybrid = 1 the hybrid form, 0 the ordinary passes (also
  * where the hybrid form was not tried).  Reads the device's verdict back: synchronises the stream. */
 LSDSORT_API int lsdsort_workspace_form(const void* d_workspace, void* hip_stream, int* hybrid);
+/* lsdsort_u32_device for a SHARD of a range-partitioned array: every key is expected to agree with the others on its top
+ * `common_prefix_bits` bits (0 .. 8) -- what a rank holds after the MSB-bucket exchange of the multi-GPU sort (north_star;
+ * csrc/sharded.hip calls this).  A hint, not a promise: the result is the sorted array whatever the keys are.  What it changes
+ * is the hybrid form's plan: its buckets are taken below the prefix (with the prefix inside them a shard's 2^15 buckets would be
+ * 2^(15 - prefix) non-empty ones, each 2^prefix times too large for the local stage, and the form would be refused); the upfront
+ * read checks every key against the first and the ordinary passes run if one differs. */
+LSDSORT_API int lsdsort_u32_device_prefixed(uint32_t* d_keys, void* d_workspace, size_t workspace_bytes, size_t n, int radix_bits,
+                                            int common_prefix_bits, void* hip_stream);
 /* Runtime tuning knob for experiments: selects among the compiled tile shapes (see
  * DESIGN.md); -1 restores the default.  Returns LSDSORT_ERR_INVALID_ARG if unknown. */
 LSDSORT_API int lsdsort_set_tile_config(int radix_bits, int config_id);

@@ -35,7 +35,7 @@ constexpr int kHybridVpt = 4;              // 16-byte vectors per thread per gro
 // 65536 returning atomics on one word took 0.6 ms).  A bucket's share of a workgroup's 1024 samples is 1/32 .. 1/16 of a key: eight in one
 // bucket -- 0.8 % of all keys, two hundred times a bucket's share -- raise the flag.
 __global__ void __launch_bounds__(1024) hybrid_sample_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t bucket_shift,
-                                                             uint32_t* __restrict__ hopeless)
+                                                             uint32_t* __restrict__ hopeless, uint32_t prefix)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];   // [kHybridBuckets]
     constexpr uint32_t kSamples = 65536;
@@ -46,27 +46,30 @@ __global__ void __launch_bounds__(1024) hybrid_sample_kernel(const uint32_t* __r
     const uint32_t k = keys[(size_t)((unsigned long long)(tid * 64u + blockIdx.x) * step)];
     for (uint32_t j = tid; j < (1u << (32u - bucket_shift)); j += 1024) s_cnt[j] = 0;
     __syncthreads();
-    if (atomicAdd(&s_cnt[k >> bucket_shift], 1u) + 1u >= 8u) *hopeless = 1u;
+    const uint32_t mask = (1u << (32u - bucket_shift)) - 1u;
+    if (atomicAdd(&s_cnt[(k >> (bucket_shift - prefix)) & mask], 1u) + 1u >= 8u) *hopeless = 1u;
 }
 
-hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bits, uint32_t* hopeless, hipStream_t stream)
+hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bits, uint32_t* hopeless, hipStream_t stream, int prefix)
 {
-    if (n < 65536u * 64u || bucket_bits < 11 || (1 << bucket_bits) > kHybridBuckets) return hipErrorInvalidValue;
+    if (n < 65536u * 64u || bucket_bits < 11 || (1 << bucket_bits) > kHybridBuckets || prefix < 0 || prefix > 8) return hipErrorInvalidValue;
     const uint32_t bucket_shift = 32u - (uint32_t)bucket_bits;
     constexpr size_t lds_bytes = (size_t)kHybridBuckets * sizeof(uint32_t);
     static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_sample_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(hybrid_sample_kernel, dim3(64), dim3(1024), lds_bytes, stream, keys, n, bucket_shift, hopeless);
+    hipLaunchKernelGGL(hybrid_sample_kernel, dim3(64), dim3(1024), lds_bytes, stream, keys, n, bucket_shift, hopeless, (uint32_t)prefix);
     return hipGetLastError();
 }
 
-template <int R, bool XF>   // R: digit width of the global passes, 8 or 4.  XF: typed keys, counted as to_sortable(key, xf)
+// R: digit width of the global passes, 8 or 4.  XF: the general instance -- typed keys, counted as to_sortable(key, xf) (the
+// identity when xf is off), and / or a key prefix: buckets and digits taken `prefix` bits lower, every key checked against the first
+template <int R, bool XF>
 __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                                uint32_t region0_keys, uint32_t* __restrict__ field_a,
                                                                                uint32_t* __restrict__ bucket, uint32_t vec_chunks,
                                                                                const uint32_t* __restrict__ skip, uint32_t bucket_shift,
-                                                                               const KeyTransform xf)
+                                                                               const KeyTransform xf, uint32_t prefix, uint32_t* __restrict__ violated)
 {
     if (skip && *skip != 0u) return;   // uniform: the sample has ruled the hybrid form out (the planner then sees no counts: not ok)
     // 8-bit digits: the first pass's field, [8 position regions][256 digits], two lane-class copies.  4-bit digits: the JOINT field
@@ -82,10 +85,14 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
     for (uint32_t j = tid; j < FA * CA + NB; j += T) s_mem[j] = 0;
     __syncthreads();
 
-    auto slot_a = [&](uint32_t k, uint32_t region0) -> uint32_t { return ((region0 << 8) | ((k >> 16) & 0xFFu)) * CA; };
+    const uint32_t a_shift = XF ? 16u - prefix : 16u, b_shift = XF ? bucket_shift - prefix : bucket_shift, b_mask = NB - 1u;
+    auto slot_a = [&](uint32_t k, uint32_t region0) -> uint32_t { return ((region0 << 8) | ((k >> a_shift) & 0xFFu)) * CA; };
+    auto slot_b = [&](uint32_t k) -> uint32_t { return XF ? (k >> b_shift) & b_mask : k >> bucket_shift; };
+    const uint32_t kref = XF && n ? to_sortable(keys[0], xf) : 0u;
+    uint32_t differs = 0;   // XF: OR of (key ^ first key) over this thread's keys -- the prefix check
     auto count_plain = [&](uint32_t k, uint32_t region0) {
         atomicAdd(&s_a[slot_a(k, region0) + copy], 1u);
-        atomicAdd(&s_b[k >> bucket_shift], 1u);
+        atomicAdd(&s_b[slot_b(k)], 1u);
     };
     uint32_t key1 = 0, key2 = 0;   // sticky heavy-key candidates (uniform)
     bool have1 = false, have2 = false;
@@ -122,6 +129,7 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
         for (int u = 0; u < VPT; u++) {
             const uint32_t region0 = ((c + (uint32_t)u) * (uint32_t)(T * 4)) / region0_keys;   // a chunk lies in one region
             const uint32_t k4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            if (XF) differs |= (k4[0] ^ kref) | (k4[1] ^ kref) | (k4[2] ^ kref) | (k4[3] ^ kref);
             if (have1) {
                 uint32_t n1 = 0, n2 = 0;
 #pragma unroll
@@ -134,11 +142,11 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
                 if (lane == 0) {
                     if (n1) {
                         atomicAdd(&s_a[slot_a(key1, region0)], n1);
-                        atomicAdd(&s_b[key1 >> bucket_shift], n1);
+                        atomicAdd(&s_b[slot_b(key1)], n1);
                     }
                     if (n2) {
                         atomicAdd(&s_a[slot_a(key2, region0)], n2);
-                        atomicAdd(&s_b[key2 >> bucket_shift], n2);
+                        atomicAdd(&s_b[slot_b(key2)], n2);
                     }
                 }
                 continue;
@@ -163,12 +171,12 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
 #pragma unroll
                     for (int q = 0; q < 4; q++) atomicAdd(&s_a[slot_a(k4[q], region0) + copy], 1u);
                 }
-                const uint32_t b0 = k4[0] >> bucket_shift, b_first = (uint32_t)__builtin_amdgcn_readfirstlane(b0);
+                const uint32_t b0 = slot_b(k4[0]), b_first = (uint32_t)__builtin_amdgcn_readfirstlane(b0);
                 if ((uint32_t)__builtin_popcountll(__ballot(b0 == b_first)) >= 16u) {
                     uint32_t held = 0;
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const uint32_t sb = k4[q] >> bucket_shift;
+                        const uint32_t sb = slot_b(k4[q]);
                         const bool h = sb == b_first;
                         held += (uint32_t)__builtin_popcountll(__ballot(h));
                         if (!h) atomicAdd(&s_b[sb], 1u);
@@ -176,7 +184,7 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
                     if (lane == 0) atomicAdd(&s_b[b_first], held);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) atomicAdd(&s_b[k4[q] >> bucket_shift], 1u);
+                    for (int q = 0; q < 4; q++) atomicAdd(&s_b[slot_b(k4[q])], 1u);
                 }
             }
         }
@@ -213,7 +221,12 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
     }
     // tail (and everything, for a base that is not 16-byte aligned: vec_chunks == 0): one key per thread per step
     for (size_t i = (size_t)full_chunks * (T * 4) + (size_t)blockIdx.x * T + tid; i < n; i += (size_t)gridDim.x * T)
-        count_plain(XF ? to_sortable(keys[i], xf) : keys[i], (uint32_t)(i / region0_keys));
+    {
+        const uint32_t k = XF ? to_sortable(keys[i], xf) : keys[i];
+        if (XF) differs |= k ^ kref;
+        count_plain(k, (uint32_t)(i / region0_keys));
+    }
+    if (XF && prefix && violated && (differs >> (32u - prefix)) != 0u) *violated = 1u;   // benign race: everybody writes 1
     __syncthreads();
     for (uint32_t j = tid; j < FA; j += T) {
         uint32_t cnt = 0;
@@ -233,8 +246,9 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
 }
 
 hipError_t launch_hybrid_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field_a, uint32_t* bucket,
-                                    int bucket_bits, const uint32_t* skip, hipStream_t stream, const KeyTransform& xf)
+                                    int bucket_bits, const uint32_t* skip, hipStream_t stream, const KeyTransform& xf, int prefix, uint32_t* violated)
 {
+    if (prefix < 0 || prefix > 8 || (prefix > 0 && !violated)) return hipErrorInvalidValue;
     if (bucket_bits < 11 || (1 << bucket_bits) > kHybridBuckets || (radix_bits != 8 && radix_bits != 4)) return hipErrorInvalidValue;
     constexpr int T = kHybridHistThreads;
     constexpr size_t lds_bytes = (size_t)(4096 + kHybridBuckets) * sizeof(uint32_t);
@@ -257,11 +271,12 @@ hipError_t launch_hybrid_histograms(int radix_bits, const uint32_t* keys, uint32
     uint32_t blocks = aligned ? (vec_chunks + kHybridVpt - 1) / kHybridVpt : (n + T * 16 - 1) / (T * 16);
     if (blocks > 256) blocks = 256;
     if (blocks == 0) blocks = 1;
-#define LSD_HYB_HIST(R, XF) hipLaunchKernelGGL((hybrid_histograms_kernel<R, XF>), dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks, skip, 32u - (uint32_t)bucket_bits, xf)
+#define LSD_HYB_HIST(R, XF) hipLaunchKernelGGL((hybrid_histograms_kernel<R, XF>), dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks, skip, 32u - (uint32_t)bucket_bits, xf, (uint32_t)prefix, violated)
+    const bool general = xf.on || prefix > 0;
     if (radix_bits == 8) {
-        if (xf.on) LSD_HYB_HIST(8, true); else LSD_HYB_HIST(8, false);
+        if (general) LSD_HYB_HIST(8, true); else LSD_HYB_HIST(8, false);
     } else {
-        if (xf.on) LSD_HYB_HIST(4, true); else LSD_HYB_HIST(4, false);
+        if (general) LSD_HYB_HIST(4, true); else LSD_HYB_HIST(4, false);
     }
 #undef LSD_HYB_HIST
     return hipGetLastError();
@@ -355,7 +370,7 @@ __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __res
     }
     if (tid == 0) {
         bases[1024 * PER] = n;
-        const uint32_t ok = (largest <= (uint32_t)kLocalSortCap && total == n) ? 1u : 0u;
+        const uint32_t ok = (largest <= (uint32_t)kLocalSortCap && total == n && words[kHybridWordViolated] == 0u) ? 1u : 0u;
         words[kHybridWordOk] = ok;            // the ordinary form's kernels return at once when this is set
         words[kHybridWordSkipLocal] = ok ^ 1u;
         words[kHybridWordLargeCount] = s_large;

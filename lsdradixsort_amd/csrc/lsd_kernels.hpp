@@ -231,7 +231,8 @@ constexpr int kHybridWordPlan = 2;        // PassParams::plan of the g-th global
 constexpr int kHybridWordLargest = 10;    // the largest bucket (diagnostics)
 constexpr int kHybridWordLargeCount = 11; // buckets above the small variant's capacity: the entries of the planner's list
 constexpr int kHybridWordHopeless = 12;   // 1: a sample of the keys already shows a bucket far above the capacity: the upfront read is skipped
-constexpr int kHybridWords = 13;
+constexpr int kHybridWordViolated = 13;   // 1: the caller's common key prefix does not hold (some key differs in its top bits): ordinary form
+constexpr int kHybridWords = 14;
 // The global passes of the hybrid form cover bits 16-31: two at 8-bit digits, four at 4-bit digits.
 inline constexpr int hybrid_global_passes(int radix_bits) { return 16 / radix_bits; }
 // Count words of the form (zeroed with the workspace): the passes' [pass][digit][region] fields (8-bit: A from the upfront read,
@@ -243,16 +244,20 @@ inline constexpr size_t hybrid_count_words(int radix_bits) { return hybrid_field
 // A look at 65536 keys taken at a regular stride: *hopeless = 1 if some bucket holds 0.8 % or more of a workgroup's 1024 samples
 // (its share is 0.003 %): such keys cannot take the hybrid form, and the 0.2-0.3 ms of its upfront read are saved (zeros, a default
 // value, small ranges, few-valued keys).
-hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bits, uint32_t* hopeless, hipStream_t stream);
+// `prefix` (here and below): the number of top bits every key is expected to share (a shard of an array partitioned by its top
+// bits).  Buckets are then the bucket_bits bits BELOW the prefix, the global passes' digits start at bit 16 - prefix.
+hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bits, uint32_t* hopeless, hipStream_t stream, int prefix = 0);
 // 8-bit digits: field[(digit of bits 16-23) * 8 + position region]; 4-bit digits: field[position region * 256 + bits 16-23] (the
 // joint field); and bucket[key >> (32 - bucket_bits)] += counts (all zero on entry).  *skip != 0: nothing
 // xf: the keys are counted as to_sortable(key, xf) (typed sorts: what the first global pass will store)
 hipError_t launch_hybrid_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field, uint32_t* bucket,
-                                    int bucket_bits, const uint32_t* skip, hipStream_t stream, const KeyTransform& xf = KeyTransform{});
+                                    int bucket_bits, const uint32_t* skip, hipStream_t stream, const KeyTransform& xf = KeyTransform{},
+                                    int prefix = 0, uint32_t* violated = nullptr);   // *violated |= 1 if a key differs from the first in its top `prefix` bits
 // verdict, bucket bases (2^bucket_bits + 1 words), plan words and the count fields the upfront read has not written: 8-bit digits
 // fields_out = the second pass's field B [256][8] (joint unused); 4-bit digits fields_out = all four passes' [4][16][16], from
 // joint and the buckets
 // ... and large_list[0 .. words[kHybridWordLargeCount]): the buckets of more than small_cap keys (up to 2^bucket_bits words)
+// words[kHybridWordViolated] != 0 on entry (the upfront read's check of the key prefix): not ok
 hipError_t launch_hybrid_plan(int radix_bits, const uint32_t* bucket, uint32_t n, int bucket_bits, uint32_t* bases, uint32_t* fields_out,
                               const uint32_t* joint, uint32_t* words, uint32_t* large_list, uint32_t small_cap, hipStream_t stream);
 

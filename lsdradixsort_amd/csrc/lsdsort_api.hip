@@ -354,8 +354,10 @@ constexpr int kMaxFeedEvents = (int)(((size_t)LSDSORT_MAX_KEYS >> 22) + 3);
 int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, size_t n, int radix_bits,
              int algorithm, hipStream_t stream, StageEvents* ev, lsdsort_timing* timing,
              const lsd::KeyTransform& xf = lsd::KeyTransform{}, const HostFeed* feed = nullptr,
-             uint32_t* const* d_more = nullptr, int more = 0)   // further payload arrays (0..2), chained form only
+             uint32_t* const* d_more = nullptr, int more = 0,   // further payload arrays (0..2), chained form only
+             int prefix = 0)   // top bits the keys are expected to share (lsdsort_u32_device_prefixed): a hint for the hybrid form's plan
 {
+    if (prefix < 0 || prefix > 8) return LSDSORT_ERR_INVALID_ARG;
     if (more < 0 || more > 2 || (more > 0 && (!d_vals || !d_more || algorithm != LSDSORT_ALGO_ONESWEEP || feed))) return LSDSORT_ERR_INVALID_ARG;
     for (int e = 0; e < more; e++)
         if (n > 0 && !d_more[e]) return LSDSORT_ERR_INVALID_ARG;
@@ -428,9 +430,9 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             uint32_t* joint = fields + lsd::hybrid_field_words(radix_bits);
             uint32_t* bucket = joint + lsd::hybrid_joint_words(radix_bits);
             const int bb = lsd::hybrid_bucket_bits(n);
-            LSD_HIP(lsd::launch_hybrid_sample(d_keys, (uint32_t)n, bb, hyb + lsd::kHybridWordHopeless, stream));
+            LSD_HIP(lsd::launch_hybrid_sample(d_keys, (uint32_t)n, bb, hyb + lsd::kHybridWordHopeless, stream, prefix));
             LSD_HIP(lsd::launch_hybrid_histograms(radix_bits, d_keys, (uint32_t)n, L.region0, radix_bits == 8 ? fields : joint, bucket, bb,
-                                                  hyb + lsd::kHybridWordHopeless, stream, xf));
+                                                  hyb + lsd::kHybridWordHopeless, stream, xf, prefix, hyb + lsd::kHybridWordViolated));
             uint32_t* bases = reinterpret_cast<uint32_t*>(ws + L.hyb_bases);
             LSD_HIP(lsd::launch_hybrid_plan(radix_bits, bucket, (uint32_t)n, bb, bases, radix_bits == 8 ? fields + 2048 : fields, joint, hyb,
                                             bases + lsd::kHybridBuckets + 1,
@@ -495,7 +497,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
                 p.vals_out = alt_vals;
                 p.num_payloads = pairs ? 1u : 0u;
                 p.n = (uint32_t)n;
-                p.shift = (uint32_t)(16 + radix_bits * g);
+                p.shift = (uint32_t)(16 - prefix + radix_bits * g);   // bits [16 - prefix, 32 - prefix): the prefix above them is constant
                 p.num_tiles = L.rows;
                 p.fault = control;
                 p.spin_limit = g_spin_limit.load(std::memory_order_relaxed);
@@ -517,8 +519,9 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             lp.bases = reinterpret_cast<const uint32_t*>(ws + L.hyb_bases);
             const int bb = lsd::hybrid_bucket_bits(n);
             lp.num_buckets = 1u << bb;
-            lp.shift[0] = 0; lp.width[0] = 9;      // bits 0-8, then 9-16 (or 9-17): the 17 (18) bits below a bucket's own
-            lp.shift[1] = 9; lp.width[1] = (uint32_t)(32 - bb - 9);
+            const int low_bits = 32 - prefix - bb;   // the 17 (18) bits below a bucket's own, fewer under a prefix: bits 0-8, then the rest
+            lp.shift[0] = 0; lp.width[0] = 9;
+            lp.shift[1] = 9; lp.width[1] = (uint32_t)(low_bits - 9);
             lp.skip = hyb + lsd::kHybridWordSkipLocal;
             lp.xout = xf;
             lp.fault = control;
@@ -950,6 +953,13 @@ int lsdsort_u32_device(uint32_t* d_keys, void* d_workspace, size_t workspace_byt
 {
     return lsdsort_u32_device_ex(d_keys, nullptr, d_workspace, workspace_bytes, n, radix_bits, LSDSORT_ALGO_ONESWEEP,
                                  hip_stream);
+}
+
+int lsdsort_u32_device_prefixed(uint32_t* d_keys, void* d_workspace, size_t workspace_bytes, size_t n, int radix_bits,
+                                int common_prefix_bits, void* hip_stream)
+{
+    return run_sort(d_keys, nullptr, d_workspace, workspace_bytes, n, radix_bits, LSDSORT_ALGO_ONESWEEP, static_cast<hipStream_t>(hip_stream),
+                    nullptr, nullptr, lsd::KeyTransform{}, nullptr, nullptr, 0, common_prefix_bits);
 }
 
 int lsdsort_pairs_u32_device(uint32_t* d_keys, uint32_t* d_vals, void* d_workspace, size_t workspace_bytes, size_t n,

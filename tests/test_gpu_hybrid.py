@@ -213,3 +213,44 @@ def test_typed_keys_take_the_hybrid_form(gpu, key_type, descending, radix, log2n
                 assert torch.equal(v2, v)
         finally:
             gpu.set_hybrid(True)
+
+
+@pytest.mark.parametrize("prefix,radix,log2n", [(1, 8, 27), (3, 8, 27), (3, 8, 26), (4, 8, 28), (3, 4, 27), (8, 8, 26)])
+def test_prefixed_shard_takes_the_hybrid_form(gpu, prefix, radix, log2n):
+    """lsdsort_u32_device_prefixed: a shard of a range-partitioned array (every key carries the same top `prefix` bits, as after
+    the MSB-bucket exchange of the multi-GPU sort).  With the hint the hybrid form plans its buckets below the prefix and runs;
+    without it the same keys fill 2^(15 - prefix) buckets 2^prefix times too large and the ordinary passes run.  Same result, equal
+    to torch.sort.  A hint that does not hold (uniform keys, prefix claimed) is caught by the upfront read: ordinary passes."""
+    import torch
+
+    n = (1 << log2n) + 777
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5 + prefix + log2n)
+    base = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda", generator=gen)
+    top = (0xA5 >> (8 - prefix)) << (32 - prefix)                       # some prefix value with its top bit set
+    keys = _i32((_u64(base) >> prefix) | top)
+    expect = torch.sort(_u64(keys)).values
+    ws = gpu.alloc_workspace(n, radix)
+    stream = torch.cuda.current_stream().cuda_stream
+    L = gpu.lib()
+
+    d = keys.clone()
+    assert L.lsdsort_u32_device_prefixed(d.data_ptr(), ws.data_ptr(), ws.numel(), n, radix, prefix, stream) == 0
+    assert gpu.workspace_form(ws) == 1, "with the hint the hybrid form runs"
+    assert L.lsdsort_check_device(ws.data_ptr(), stream) == 0
+    assert torch.equal(_u64(d), expect)
+
+    d = keys.clone()
+    assert L.lsdsort_u32_device_prefixed(d.data_ptr(), ws.data_ptr(), ws.numel(), n, radix, 0, stream) == 0
+    # without the hint: non-empty buckets are 2^prefix times the average -- 8192 keys at (prefix 1, 2^27 keys) still fit
+    assert gpu.workspace_form(ws) == (1 if (prefix, log2n) == (1, 27) else 0)
+    assert torch.equal(_u64(d), expect)
+
+    # the hint does not hold: one key elsewhere, then uniform keys
+    for wrong in (torch.cat([keys[:-1], _i32(torch.tensor([5], device="cuda", dtype=torch.int64))]), base):
+        d = wrong.clone()
+        assert L.lsdsort_u32_device_prefixed(d.data_ptr(), ws.data_ptr(), ws.numel(), n, radix, prefix, stream) == 0
+        assert gpu.workspace_form(ws) == 0, "a key outside the prefix: the ordinary passes"
+        assert L.lsdsort_check_device(ws.data_ptr(), stream) == 0
+        assert torch.equal(_u64(d), torch.sort(_u64(wrong)).values)
+    assert L.lsdsort_u32_device_prefixed(d.data_ptr(), ws.data_ptr(), ws.numel(), n, radix, 9, stream) != 0

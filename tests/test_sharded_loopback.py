@@ -181,3 +181,30 @@ def test_sub_bucket_argument_checks(gpu):
         assert all(st in (errors.LSDSORT_ERR_UNSUPPORTED, errors.LSDSORT_ERR_COMM) for st, _, _ in res), [st for st, _, _ in res]
     finally:
         lw.close()
+
+
+def test_step_at_hybrid_sizes(gpu):
+    """Two virtual ranks of 2^26 + ... keys each under the MSB partition: every rank's received shard (about 2^26 keys that share
+    their top bit) is of the size where the local sort tries the hybrid form, planned below the shard's prefix
+    (lsdsort_u32_device_prefixed).  The rank-order concatenation is the sorted union."""
+    import torch
+
+    world = 2
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(2026)
+    dev = [torch.randint(-(1 << 31), (1 << 31) - 1, ((1 << 26) + 4099 * (r + 1),), dtype=torch.int32, device="cuda", generator=gen)
+           for r in range(world)]
+    union = torch.sort(torch.cat([(d.to(torch.int64) & 0xFFFFFFFF) for d in dev])).values
+    from lsdradixsort_amd.dist import LoopbackWorld
+
+    lw = LoopbackWorld(world, 8, 1)
+    try:
+        res = lw.step(dev, partition="msb")
+        pieces = []
+        for r, (st, out, n_out) in enumerate(res):
+            assert st == 0, (r, st)
+            assert out.keys.numel() == n_out
+            pieces.append(out.keys.to(torch.int64) & 0xFFFFFFFF)
+        assert torch.equal(torch.cat(pieces), union)
+    finally:
+        lw.close()
