@@ -254,3 +254,33 @@ def test_prefixed_shard_takes_the_hybrid_form(gpu, prefix, radix, log2n):
         assert L.lsdsort_check_device(ws.data_ptr(), stream) == 0
         assert torch.equal(_u64(d), torch.sort(_u64(wrong)).values)
     assert L.lsdsort_u32_device_prefixed(d.data_ptr(), ws.data_ptr(), ws.numel(), n, radix, 9, stream) != 0
+
+
+def test_hybrid_in_a_hip_graph_and_from_an_unaligned_base(gpu):
+    """The form is chosen on the device from plan words in the workspace, so a captured sort chooses anew at every replay: one
+    graph, replayed on keys the hybrid form takes (uniform) and on keys it must refuse (half zeros).  The key array starts one
+    word past a 16-byte boundary: the upfront read takes its scalar path, the passes and the local stage their ragged edges."""
+    import torch
+
+    n = (1 << 26) + 4242
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(11)
+    backing = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    static_k = backing[1:]
+    assert static_k.data_ptr() % 16 == 4
+    ws = gpu.alloc_workspace(n, 8)
+    uniform = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda", generator=gen)
+    half_zero = torch.where((uniform & 0x2000) != 0, uniform, torch.zeros_like(uniform))
+    static_k.copy_(uniform)
+    gpu.GPULSDRadixSort(static_k, 8, workspace=ws)                        # warm-up outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        gpu.GPULSDRadixSort(static_k, 8, workspace=ws)
+    for keys, form in ((uniform, 1), (half_zero, 0), (uniform, 1)):
+        static_k.copy_(keys)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert gpu.workspace_form(ws) == form
+        assert torch.equal(_u64(static_k), torch.sort(_u64(keys)).values), form
+        assert gpu.lib().lsdsort_check_device(ws.data_ptr(), None) == 0
