@@ -171,7 +171,7 @@ __device__ __forceinline__ void sort_bucket(const LocalSortParams& p, const uint
 // registers: three workgroups per CU need 80 or fewer (keys K <= 20; pairs K <= 16), two 128; the 16384-pair variant keeps three
 // arrays of 32 and gets 256 (one workgroup per CU: it only ever sees the planner's list of outsized buckets)
 template <int K, bool PAIRS>
-constexpr int local_waves_per_simd() { return (PAIRS ? K <= 16 : K <= 20) ? 6 : (PAIRS ? 2 : 4); }
+constexpr int local_waves_per_simd() { return K <= 10 ? 8 : (PAIRS ? K <= 16 : K <= 20) ? 6 : (PAIRS ? 2 : 4); }
 
 // one bucket per workgroup
 template <int K, bool PAIRS, bool XOUT>
@@ -232,6 +232,10 @@ hipError_t launch_local_sort(const LocalSortParams& p, hipStream_t stream)
         if (p.width[i] > 9 || (p.width[i] && p.shift[i] + p.width[i] > 32)) return hipErrorInvalidValue;
     if ((p.list == nullptr) != (p.list_count == nullptr)) return hipErrorInvalidValue;
     if (p.small_variant && p.list) return hipErrorInvalidValue;   // the list is the large variant's
+    if (p.small_variant == 2) {
+        if (p.vals) return launch_local_inst<kLocalSortCapTiny / kLocalThreads, true>(p, stream);
+        return launch_local_inst<kLocalSortCapTiny / kLocalThreads, false>(p, stream);
+    }
     if (p.vals) {
         if (p.small_variant) return launch_local_inst<kLocalSortCapSmallPairs / kLocalThreads, true>(p, stream);
         return launch_local_inst<32, true>(p, stream);

@@ -203,6 +203,7 @@ hipError_t launch_tile_offsets(int radix_bits, const uint32_t* hist, uint32_t* l
 constexpr int kLocalSortCap = 16384;
 constexpr int kLocalSortCapSmall = 10240;   // the three-workgroups-per-CU variant (small_variant), keys only
 constexpr int kLocalSortCapSmallPairs = 8192;   // ... with payloads (a third register per pair)
+constexpr int kLocalSortCapTiny = 5120;         // small_variant 2: four workgroups per CU (keys and pairs)
 struct LocalSortParams {
     uint32_t* keys;
     uint32_t* vals;              // null: keys only.  Else a payload word per key, permuted with it (stable)
@@ -211,7 +212,7 @@ struct LocalSortParams {
     uint32_t shift[3], width[3];
     const uint32_t* skip;
     uint32_t* fault;
-    uint32_t small_variant;   // 1: buckets of up to kLocalSortCapSmall keys, three workgroups per CU
+    uint32_t small_variant;   // 1: buckets of up to kLocalSortCapSmall keys, three workgroups per CU; 2: up to kLocalSortCapTiny, four
     uint32_t larger_elsewhere;   // 1: a bucket above this launch's capacity is another launch's (no fault)
     KeyTransform xout;           // typed sorts: the stage's store turns the sortable keys back (from_sortable)
     const uint32_t* list;        // null: bucket = workgroup index.  Else the buckets to sort, *list_count of them, walked by a
@@ -220,10 +221,18 @@ struct LocalSortParams {
 hipError_t launch_local_sort(const LocalSortParams& p, hipStream_t stream);
 
 // ---- the hybrid form's upfront read and planner (hybrid.hip) ------------------------------------------------------------
-// A bucket = the keys that agree on their top `bucket_bits` bits: 15 for 2^27 keys and more, 14 below (the average bucket stays
-// between 4096 and 14648 keys).  Every table is sized for 2^15.
+// A bucket = the keys that agree on their top `bucket_bits` bits: 14 while what uniform keys put into one of 2^14 buckets (mean
+// + 6 sigma) fits the three-per-CU variant of the local stage (10240 keys, 8192 pairs), 15 above.  Larger buckets are cheaper per
+// key (a bucket's scans, barriers and its unoverlapped first load and last store are per bucket: 2^27 keys in buckets of 4096 cost
+// the local stage 0.35-0.39 ms, in buckets of 8192 0.29).  Every table is sized for 2^15.
 constexpr int kHybridBuckets = 1 << 15;
-inline constexpr int hybrid_bucket_bits(size_t n) { return n >= ((size_t)1 << 27) ? 15 : 14; }
+constexpr int hybrid_bucket_bits(size_t n, bool pairs)
+{
+    const size_t mean = n >> 14, cap = pairs ? 8192 : 10240;
+    size_t root = 1;                               // ceil(sqrt(mean)), no <cmath> in device headers
+    while (root * root < mean) root++;
+    return mean + 6 * root <= cap ? 14 : 15;
+}
 // plan words (uint32, in the workspace's control block): written by the planner, read by every kernel of either form
 constexpr int kHybridWordOk = 0;          // 1: the hybrid form runs (the ordinary form's kernels return at once)
 constexpr int kHybridWordSkipLocal = 1;   // 1: the local stage returns at once (both launches)

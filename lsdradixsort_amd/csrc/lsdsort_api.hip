@@ -51,6 +51,15 @@ std::atomic<int> g_hybrid{[] {                                          // lsdso
 // device from the exact bucket counts.
 constexpr size_t kHybridMinKeys = (size_t)1 << 26;
 constexpr size_t kHybridMaxKeys = (size_t)480 * 1000 * 1000;
+// The capacity of the local stage's launch over all buckets: the smallest variant that holds what uniform keys put into a bucket
+// (mean + 6 sigma); larger buckets go on the planner's list for the 16384-key variant.
+int hybrid_small_cap(size_t n, bool pairs)
+{
+    static const bool tiny = [] { const char* e = getenv("LSDSORT_LOCAL_TINY"); return !(e && e[0] == '0'); }();   // experiment knob
+    const double mean = (double)(n >> lsd::hybrid_bucket_bits(n, pairs));
+    if (tiny && mean + 6.0 * std::sqrt(mean) <= (double)lsd::kLocalSortCapTiny) return lsd::kLocalSortCapTiny;
+    return pairs ? lsd::kLocalSortCapSmallPairs : lsd::kLocalSortCapSmall;
+}
 std::atomic<int> g_skip_dead_passes{[] {                                // lsdsort_set_pass_skipping; LSDSORT_PASS_SKIPPING=0 starts it off
     const char* e = getenv("LSDSORT_PASS_SKIPPING");
     return (e && e[0] == '0') ? 0 : 1;
@@ -410,7 +419,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     // never skips a pass.
     const bool try_hybrid = algorithm == LSDSORT_ALGO_ONESWEEP && (radix_bits == 8 || radix_bits == 4) && more == 0 && !feed &&
                             rank_method == lsd::kRankLdsAdd && n >= kHybridMinKeys && n <= kHybridMaxKeys &&
-                            (n >> lsd::hybrid_bucket_bits(n)) <= 14648 && shape->tile() == 32768 && g_hybrid.load(std::memory_order_relaxed);
+                            (n >> lsd::hybrid_bucket_bits(n, pairs)) <= 14648 && shape->tile() == 32768 && g_hybrid.load(std::memory_order_relaxed);
     uint32_t* plan = nullptr;
     if (algorithm == LSDSORT_ALGO_ONESWEEP && (!xf.on || try_hybrid) && 2 * passes + 1 <= lsd::kPlanWords &&
         g_skip_dead_passes.load(std::memory_order_relaxed))
@@ -429,14 +438,14 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             uint32_t* fields = reinterpret_cast<uint32_t*>(ws + L.hyb_counts);
             uint32_t* joint = fields + lsd::hybrid_field_words(radix_bits);
             uint32_t* bucket = joint + lsd::hybrid_joint_words(radix_bits);
-            const int bb = lsd::hybrid_bucket_bits(n);
+            const int bb = lsd::hybrid_bucket_bits(n, pairs);
             LSD_HIP(lsd::launch_hybrid_sample(d_keys, (uint32_t)n, bb, hyb + lsd::kHybridWordHopeless, stream, prefix));
             LSD_HIP(lsd::launch_hybrid_histograms(radix_bits, d_keys, (uint32_t)n, L.region0, radix_bits == 8 ? fields : joint, bucket, bb,
                                                   hyb + lsd::kHybridWordHopeless, stream, xf, prefix, hyb + lsd::kHybridWordViolated));
             uint32_t* bases = reinterpret_cast<uint32_t*>(ws + L.hyb_bases);
             LSD_HIP(lsd::launch_hybrid_plan(radix_bits, bucket, (uint32_t)n, bb, bases, radix_bits == 8 ? fields + 2048 : fields, joint, hyb,
                                             bases + lsd::kHybridBuckets + 1,
-                                            (uint32_t)(pairs ? lsd::kLocalSortCapSmallPairs : lsd::kLocalSortCapSmall), stream));
+                                            (uint32_t)hybrid_small_cap(n, pairs), stream));
             // the global passes' region tables: the first one's regions are by position (like any first pass), the others' by the
             // top bits of the digit before -- exactly what stage 2 builds for consecutive passes
             // (no fault word: where the sample or the planner has said no these counts are partial or absent, and nobody uses the tables)
@@ -517,7 +526,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             lp.keys = d_keys;
             lp.vals = d_vals;
             lp.bases = reinterpret_cast<const uint32_t*>(ws + L.hyb_bases);
-            const int bb = lsd::hybrid_bucket_bits(n);
+            const int bb = lsd::hybrid_bucket_bits(n, pairs);
             lp.num_buckets = 1u << bb;
             const int low_bits = 32 - prefix - bb;   // the 17 (18) bits below a bucket's own, fewer under a prefix: bits 0-8, then the rest
             lp.shift[0] = 0; lp.width[0] = 9;
@@ -526,7 +535,9 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             lp.xout = xf;
             lp.fault = control;
             if (ev) LSD_TRY(ev->mark());
-            lp.small_variant = 1;     // buckets of up to 10240 keys (all of them on uniform keys of these sizes): three workgroups per CU
+            // buckets of up to 10240 keys (all of them on uniform keys of most sizes): three workgroups per CU; where uniform keys
+            // stay under 5120 a bucket, four
+            lp.small_variant = hybrid_small_cap(n, pairs) == lsd::kLocalSortCapTiny ? 2u : 1u;
             lp.larger_elsewhere = 1;
             LSD_HIP(lsd::launch_local_sort(lp, stream));
             lp.small_variant = 0;     // the planner's list of larger ones (up to 16384 keys): two per CU, a grid of 512 walks the list

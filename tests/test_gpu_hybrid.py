@@ -64,7 +64,7 @@ def test_hybrid_equals_torch_sort_and_the_four_pass_form(gpu, log2n, extra, radi
     import torch
 
     n = (1 << log2n) + extra
-    bb = 15 if log2n >= 27 else 14          # bucket = the top bb bits (lsd_kernels.hpp hybrid_bucket_bits)
+    bb = 15 if log2n >= 28 else 14          # bucket = the top bb bits (lsd_kernels.hpp hybrid_bucket_bits: keys, 2^26 .. 2^27 -> 14)
     sh, low = 32 - bb, (1 << (32 - bb)) - 1
     gen = torch.Generator(device="cuda")
     gen.manual_seed(4000 + log2n + extra)
@@ -169,10 +169,11 @@ def test_typed_keys_take_the_hybrid_form(gpu, key_type, descending, radix, log2n
     gen.manual_seed(99 + log2n + radix)
     bits = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda", generator=gen)
     if key_type == "float32":
-        # NaN / inf patterns (exponent 0xFF, 0.4 % of random bits) become finite values of their own: one replacement value for
-        # all of them would be a bucket of 2^18 equal keys, which the planner rightly refuses
+        # NaN / inf patterns (exponent 0xFF, 0.4 % of random bits) become finite values spread over 128 exponents (taken from their
+        # own low mantissa bits): one replacement value, or one replacement exponent, would be buckets of twice and more the
+        # average, which the planner rightly refuses
         bad = ((bits >> 23) & 0xFF) == 0xFF
-        bits = torch.where(bad, bits & ~(1 << 30), bits)
+        bits = torch.where(bad, (bits & ~(0xFF << 23)) | ((bits & 0x7F) << 23), bits)
         keys = bits.view(torch.float32).clone()
         keys[:4] = torch.tensor([0.0, -0.0, float("inf"), float("-inf")], device="cuda")
     else:
@@ -242,8 +243,8 @@ def test_prefixed_shard_takes_the_hybrid_form(gpu, prefix, radix, log2n):
 
     d = keys.clone()
     assert L.lsdsort_u32_device_prefixed(d.data_ptr(), ws.data_ptr(), ws.numel(), n, radix, 0, stream) == 0
-    # without the hint: non-empty buckets are 2^prefix times the average -- 8192 keys at (prefix 1, 2^27 keys) still fit
-    assert gpu.workspace_form(ws) == (1 if (prefix, log2n) == (1, 27) else 0)
+    # without the hint: non-empty buckets are 2^prefix times the average -- 16384 keys and more
+    assert gpu.workspace_form(ws) == 0
     assert torch.equal(_u64(d), expect)
 
     # the hint does not hold: one key elsewhere, then uniform keys
