@@ -168,6 +168,170 @@ __device__ __forceinline__ void sort_bucket(const LocalSortParams& p, const uint
     }
 }
 
+// Several payload arrays (records: lsdsort_multi_u32_device): carrying each of them through every digit pass, as PAIRS does with
+// its one, would cost two LDS round trips per array and pass and a register array each.  Instead the KEYS are sorted first (as in
+// the keys-only kernel, remembering each element's slot after the first pass), the second pass's slots are left in LDS indexed by
+// position, and one random LDS read per element composes the two: final[i] = slot2[slot1[i]].  Each payload array then takes ONE
+// trip: loaded in position order, written to its elements' final slots, stored linearly -- in place, the bucket being this
+// workgroup's alone (every load of an array is in registers before the barrier that precedes its first store).  At most two
+// digit passes (the hybrid form's local stage has two).
+template <int K>
+__device__ __forceinline__ void sort_bucket_multi(const LocalSortParams& p, const uint32_t b)
+{
+    constexpr int T = kLocalThreads, W = kLocalWaves, HW = kLocalMaxBins / 2;
+    constexpr int CAP = T * K;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    lds_u32* const s_keys = (lds_u32*)smem;
+    volatile lds_u32* const s_cnt = (volatile lds_u32*)(s_keys + CAP);
+    volatile lds_u16* const s_cnt16 = (volatile lds_u16*)s_cnt;
+    lds_u32* const s_misc = (lds_u32*)(s_cnt + W * HW);
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t lo = p.bases[b], hi = p.bases[b + 1];
+    const uint32_t size = hi - lo;
+    if (size == 0u || hi < lo) return;
+    if (size > (uint32_t)CAP) {
+        if (!p.larger_elsewhere && tid == 0 && p.fault) atomicOr(p.fault, 8u);
+        return;
+    }
+    uint32_t* const bucket = p.keys + lo;
+    const uint32_t rows = (size + (uint32_t)T - 1u) / (uint32_t)T;
+    const uint32_t wbase = wave * rows * 64u + lane;
+
+    uint32_t key[K], slot[K], first_slot[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        if ((uint32_t)i < rows) {
+            const uint32_t pos = wbase + (uint32_t)i * 64u;
+            key[i] = pos < size ? bucket[pos] : 0xFFFFFFFFu;
+        }
+    }
+    // one digit pass over key[] (position order): afterwards the keys lie in LDS in their new order and slot[i] says where key[i] went
+    auto digit_pass = [&](uint32_t shift, uint32_t width) {
+        const uint32_t bins = 1u << width, mask = bins - 1u;
+#pragma unroll
+        for (int j = 0; j < HW / kWave; j++) s_cnt[wave * HW + j * kWave + lane] = 0;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            if ((uint32_t)i < rows) {
+                const uint32_t d = (key[i] >> shift) & mask;
+                const uint32_t sh = (d & 1u) * 16u;
+                const uint32_t old = __hip_atomic_fetch_add((lds_u32*)&s_cnt[wave * HW + (d >> 1)], 1u << sh, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_WAVEFRONT);
+                slot[i] = (old >> sh) & 0xFFFFu;
+            }
+        }
+        __syncthreads();
+        uint32_t total = 0;
+        uint32_t wave_excl[W];
+        if (tid < bins) {
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                wave_excl[w] = total;
+                total += s_cnt16[w * kLocalMaxBins + tid];
+            }
+        }
+        uint32_t incl = wave_inclusive_scan(tid < bins ? total : 0u, lane);
+        if (lane == 63u) s_misc[wave] = incl;
+        __syncthreads();
+        uint32_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) carry += (uint32_t)w < wave ? s_misc[w] : 0u;
+        const uint32_t local_off = incl + carry - total;
+        if (tid < bins) {
+#pragma unroll
+            for (int w = 0; w < W; w++) s_cnt16[w * kLocalMaxBins + tid] = (uint16_t)(local_off + wave_excl[w]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            if ((uint32_t)i < rows) {
+                const uint32_t d = (key[i] >> shift) & mask;
+                slot[i] += (uint32_t)s_cnt16[wave * kLocalMaxBins + d];
+                s_keys[slot[i]] = key[i];
+            }
+        }
+        __syncthreads();
+    };
+    digit_pass(p.shift[0], p.width[0]);
+    if (p.width[1]) {
+#pragma unroll
+        for (int i = 0; i < K; i++)
+            if ((uint32_t)i < rows) {
+                first_slot[i] = slot[i];
+                key[i] = s_keys[wbase + (uint32_t)i * 64u];
+            }
+        digit_pass(p.shift[1], p.width[1]);
+    }
+    for (uint32_t q = tid; q < size; q += (uint32_t)T) bucket[q] = s_keys[q];   // the keys are done
+    if (p.width[1]) {
+        __syncthreads();   // the keys have left the LDS: it now holds the second pass's slots by position ...
+#pragma unroll
+        for (int i = 0; i < K; i++)
+            if ((uint32_t)i < rows) s_keys[wbase + (uint32_t)i * 64u] = slot[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < K; i++)   // ... and the element that started at position wbase + 64 i ends in slot2[slot1]
+            if ((uint32_t)i < rows) slot[i] = s_keys[first_slot[i]];
+    }
+    for (uint32_t e = 0; e < p.num_payloads; e++) {
+        uint32_t* const pay = (e == 0 ? p.vals : p.more[e - 1]) + lo;
+        __syncthreads();   // the LDS is free again (slots read, or the previous array stored)
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            if ((uint32_t)i < rows) {
+                const uint32_t pos = wbase + (uint32_t)i * 64u;
+                key[i] = pos < size ? pay[pos] : 0u;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < K; i++)
+            if ((uint32_t)i < rows) s_keys[slot[i]] = key[i];
+        __syncthreads();
+        for (uint32_t q = tid; q < size; q += (uint32_t)T) pay[q] = s_keys[q];
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(kLocalThreads, (K <= 16 ? 6 : 2)) local_sort_multi_kernel(const LocalSortParams p)
+{
+    if (p.skip && *p.skip != 0u) return;
+    sort_bucket_multi<K>(p, blockIdx.x);
+}
+
+// the planner's list, walked by a small grid (a kernel of its own: with both uses in one kernel the body is inlined twice and spills)
+template <int K>
+__global__ void __launch_bounds__(kLocalThreads, (K <= 16 ? 6 : 2)) local_sort_multi_list_kernel(const LocalSortParams p)
+{
+    if (p.skip && *p.skip != 0u) return;
+    const uint32_t listed = *p.list_count;
+    for (uint32_t item = blockIdx.x; item < listed; item += gridDim.x) {
+        sort_bucket_multi<K>(p, p.list[item]);
+        __syncthreads();
+    }
+}
+
+template <int K>
+static hipError_t launch_local_multi(const LocalSortParams& p, hipStream_t stream)
+{
+    constexpr size_t lds_bytes = local_lds_words<K>() * sizeof(uint32_t);
+    if (p.list) {
+        if constexpr (K == 32) {   // the list is the large variant's (three register arrays of 32: one workgroup per CU, as the pairs')
+            auto kernel = local_sort_multi_list_kernel<K>;
+            static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (attr != hipSuccess) return attr;
+            hipLaunchKernelGGL(kernel, dim3(256), dim3(kLocalThreads), lds_bytes, stream, p);
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+    }
+    auto kernel = local_sort_multi_kernel<K>;
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(kernel, dim3(p.num_buckets), dim3(kLocalThreads), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
 // registers: three workgroups per CU need 80 or fewer (keys K <= 20; pairs K <= 16), two 128; the 16384-pair variant keeps three
 // arrays of 32 and gets 256 (one workgroup per CU: it only ever sees the planner's list of outsized buckets)
 template <int K, bool PAIRS>
@@ -232,6 +396,11 @@ hipError_t launch_local_sort(const LocalSortParams& p, hipStream_t stream)
         if (p.width[i] > 9 || (p.width[i] && p.shift[i] + p.width[i] > 32)) return hipErrorInvalidValue;
     if ((p.list == nullptr) != (p.list_count == nullptr)) return hipErrorInvalidValue;
     if (p.small_variant && p.list) return hipErrorInvalidValue;   // the list is the large variant's
+    if (p.num_payloads > 3 || (p.num_payloads > 0 && !p.vals)) return hipErrorInvalidValue;
+    if (p.num_payloads > 1) {   // records: several payload arrays
+        if (p.width[2] || p.xout.on || !p.more[0] || (p.num_payloads > 2 && !p.more[1])) return hipErrorInvalidValue;
+        return p.small_variant ? launch_local_multi<16>(p, stream) : launch_local_multi<32>(p, stream);
+    }
     if (p.small_variant == 2) {
         if (p.vals) return launch_local_inst<kLocalSortCapTiny / kLocalThreads, true>(p, stream);
         return launch_local_inst<kLocalSortCapTiny / kLocalThreads, false>(p, stream);

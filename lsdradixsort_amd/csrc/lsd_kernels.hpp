@@ -207,6 +207,8 @@ constexpr int kLocalSortCapTiny = 5120;         // small_variant 2: four workgro
 struct LocalSortParams {
     uint32_t* keys;
     uint32_t* vals;              // null: keys only.  Else a payload word per key, permuted with it (stable)
+    uint32_t* more[2];           // further payload arrays (num_payloads 2, 3), at most two digit passes then
+    uint32_t num_payloads;       // 0 = as `vals` says (none or one)
     const uint32_t* bases;
     uint32_t num_buckets;
     uint32_t shift[3], width[3];

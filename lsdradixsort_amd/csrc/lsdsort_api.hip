@@ -417,7 +417,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     // pass carry the key transform) nor where the plan would not fit the control block.
     // A typed sort gets a plan only where the hybrid form is tried (its kernels are told by the plan which form runs), and that plan
     // never skips a pass.
-    const bool try_hybrid = algorithm == LSDSORT_ALGO_ONESWEEP && (radix_bits == 8 || radix_bits == 4) && more == 0 && !feed &&
+    const bool try_hybrid = algorithm == LSDSORT_ALGO_ONESWEEP && (radix_bits == 8 || radix_bits == 4) && !feed &&
                             rank_method == lsd::kRankLdsAdd && n >= kHybridMinKeys && n <= kHybridMaxKeys &&
                             (n >> lsd::hybrid_bucket_bits(n, pairs)) <= 14648 && shape->tile() == 32768 && g_hybrid.load(std::memory_order_relaxed);
     uint32_t* plan = nullptr;
@@ -504,7 +504,11 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
                 p.out = alt_keys;
                 p.vals_in = d_vals;
                 p.vals_out = alt_vals;
-                p.num_payloads = pairs ? 1u : 0u;
+                p.num_payloads = pairs ? (uint32_t)(1 + more) : 0u;
+                for (int e = 0; e < more; e++) {   // the plan word says which way round (as for the first payload array)
+                    p.more_in[e] = d_more[e];
+                    p.more_out[e] = reinterpret_cast<uint32_t*>(ws + L.alt_more[e]);
+                }
                 p.n = (uint32_t)n;
                 p.shift = (uint32_t)(16 - prefix + radix_bits * g);   // bits [16 - prefix, 32 - prefix): the prefix above them is constant
                 p.num_tiles = L.rows;
@@ -525,6 +529,8 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             lsd::LocalSortParams lp{};
             lp.keys = d_keys;
             lp.vals = d_vals;
+            lp.num_payloads = pairs ? (uint32_t)(1 + more) : 0u;
+            for (int e = 0; e < more; e++) lp.more[e] = d_more[e];
             lp.bases = reinterpret_cast<const uint32_t*>(ws + L.hyb_bases);
             const int bb = lsd::hybrid_bucket_bits(n, pairs);
             lp.num_buckets = 1u << bb;

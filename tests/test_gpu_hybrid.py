@@ -285,3 +285,53 @@ def test_hybrid_in_a_hip_graph_and_from_an_unaligned_base(gpu):
         assert gpu.workspace_form(ws) == form
         assert torch.equal(_u64(static_k), torch.sort(_u64(keys)).values), form
         assert gpu.lib().lsdsort_check_device(ws.data_ptr(), None) == 0
+
+
+@pytest.mark.parametrize("payloads,radix,log2n", [(2, 8, 26), (3, 8, 27), (3, 4, 26)])
+def test_several_payload_arrays_take_the_hybrid_form(gpu, payloads, radix, log2n):
+    """lsdsort_multi_u32_device at hybrid sizes (what a 64-bit-key or 64-bit-payload record sort is made of): the global passes
+    carry every payload array, the local stage sorts the keys, composes its two digit passes' slots and sends each payload array
+    through LDS once.  Keys with many duplicates inside the buckets (stability), payload e = a function of the input position:
+    torch's stable sort says where every element must end up.  On keys the form refuses (half zeros): the ordinary passes."""
+    import torch
+
+    n = (1 << log2n) + 4321
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(31 + payloads + log2n)
+    base = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda", generator=gen)
+    idx = torch.arange(n, dtype=torch.int32, device="cuda")
+    need = int(gpu.lib().lsdsort_workspace_bytes(n, radix, payloads))
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    shapes = {
+        "duplicates_in_buckets": (_i32(_u64(base) & 0xFFFC0F0F), 1),
+        "half_zero": (torch.where(((_u64(base) >> 13) & 1) != 0, base, torch.zeros_like(base)), 0),
+    }
+    for name, (keys, form) in shapes.items():
+        expect = torch.sort(_u64(keys), stable=True)
+        d = keys.clone()
+        pay = [(idx * (2 * e + 3) + e).to(torch.int32) for e in range(payloads)]          # int32 wrap-around is part of the function
+        want = [p[expect.indices] for p in pay]
+        gpu.GPUSortMulti(d, pay, r=radix, workspace=ws, check_fault=True)
+        assert gpu.workspace_form(ws) == form, (name, gpu.workspace_form(ws))
+        assert torch.equal(_u64(d), expect.values), name
+        for e in range(payloads):
+            assert torch.equal(pay[e], want[e]), (name, "payload", e)
+        del expect, want, pay, d
+
+
+def test_records_at_hybrid_size(gpu):
+    """lsdsort_records_device, 64-bit keys with 64-bit payloads, 2^26 records: two multi-payload sorts, each in the hybrid form.
+    Against torch's stable sort of the keys as unsigned 64-bit numbers (sign bit flipped); payload = input position."""
+    import torch
+
+    n = (1 << 26) + 999
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(64)
+    k = torch.randint(-(1 << 63), (1 << 63) - 1, (n,), dtype=torch.int64, device="cuda", generator=gen)
+    k[: n // 8] &= 0x0000FFFFFFFF0000                     # duplicates of high and low parts: stability across the two sorts
+    v = torch.arange(n, dtype=torch.int64, device="cuda") * 3 + 1
+    expect = torch.sort(k ^ (-(1 << 63)), stable=True)      # unsigned order
+    kk, vv = k.clone(), v.clone()
+    gpu.GPUSortWide(kk, vv, check_fault=True)
+    assert torch.equal(kk, k[expect.indices])
+    assert torch.equal(vv, v[expect.indices])
