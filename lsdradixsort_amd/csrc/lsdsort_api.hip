@@ -41,6 +41,9 @@ constexpr size_t kControlBytes = 256;            // u32[64]: [0] fault word, [16
 constexpr size_t kPlanOffsetWords = 16;
 constexpr size_t kHybridOffsetWords = kPlanOffsetWords + lsd::kPlanWords + 1;   // the hybrid form's plan words (hybrid.hip)
 static_assert(kHybridOffsetWords + lsd::kHybridWords <= kControlBytes / sizeof(uint32_t), "the plans live in the control block");
+// what the bucket rule gives BASELINE's sizes: 2^28 keys 2^15 buckets of 8192, 2^27 keys 2^14 of 8192, 2^27 pairs 2^15 of 4096
+static_assert(lsd::hybrid_bucket_bits((size_t)1 << 28, false) == 15 && lsd::hybrid_bucket_bits((size_t)1 << 27, false) == 14 &&
+              lsd::hybrid_bucket_bits((size_t)1 << 27, true) == 15 && lsd::hybrid_bucket_bits((size_t)1 << 26, true) == 14, "bucket rule");
 std::atomic<int> g_hybrid{[] {                                          // lsdsort_set_hybrid; LSDSORT_HYBRID=0 starts it off
     const char* e = getenv("LSDSORT_HYBRID");
     return (e && e[0] == '0') ? 0 : 1;
