@@ -77,8 +77,8 @@ def parse_args(argv=None):
                     help="keys of the workload the CPU baseline sorts (default: all 2^28 of config 3, about 16 s of std::sort on one core)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configs reported under 'extra'")
     ap.add_argument("--no-hybrid", action="store_true",
-                    help="keys-only 8-bit sorts: always the four global passes (lsdsort_set_hybrid(0)); default: the library decides "
-                         "on the device whether two global passes + the LDS-resident local stage can run")
+                    help="always every digit through global memory (lsdsort_set_hybrid(0)); default: the library decides on the device "
+                         "whether the global passes on bits 16-31 + the LDS-resident local stage can run")
     ap.add_argument("--sub-buckets", type=int, default=1, choices=[1, 2, 4],
                     help="N > 1: sub-bucket pipelining of the sharded step (lsdsort_comm_set_sub_buckets)")
     ap.add_argument("--no-live-traffic", action="store_true",

@@ -115,8 +115,8 @@ def set_xcd_chunk(chunk: int) -> None:
 
 
 def set_hybrid(on: bool) -> None:
-    """The hybrid form of large keys-only 8-bit sorts (two global passes + an LDS-resident local stage, decided on the
-    device; ``lsdsort_set_hybrid``).  Default on; off = always the four global passes."""
+    """The hybrid form of sorts of 2^26 .. 4.8e8 items with 8- or 4-bit digits (global passes on bits 16-31 + an LDS-resident local
+    stage, decided on the device; ``lsdsort_set_hybrid``).  Default on; off = every digit through global memory, always."""
     check(lib().lsdsort_set_hybrid(1 if on else 0), "lsdsort_set_hybrid")
 
 

@@ -1,4 +1,6 @@
-// hybrid.hip -- stage 1 and the planner of the HYBRID form of the 8-bit-digit sort (keys only, 2^27 <= n < 2^29).
+// hybrid.hip -- stage 1 and the planner of the HYBRID form (2^26 .. 4.8e8 items; 8- or 4-bit digits; keys, pairs, records; typed keys).
+// Written below for its first shape -- 8-bit digits, 2^15 buckets; what differs at 4-bit digits, with 2^14 buckets, for typed keys
+// and for shards that share a key prefix is said at the kernels.
 //
 // The reference moves every key through global memory once per digit (GPULSDRadixSort, LSDRadixSort.cu:844-905: four passes at
 // 8-bit digits), and so does this library's chained form: 4 + 4 x 8 = 36 B/key.  An MI355X CU has 160 KiB of LDS: a bucket of

@@ -8,6 +8,9 @@
 // in place.  8 B/key of HBM traffic for the low 17 bits instead of 16 B/key for two more global passes, and no chained scan:
 // buckets are independent.
 //
+// Buckets are the top 15 or the top 14 bits (lsd_kernels.hpp hybrid_bucket_bits), below a key prefix where the caller has named one;
+// 4-bit-digit sorts come here after four global passes instead of two.
+//
 // Per workgroup (T = 512 threads, up to K = 32 keys each, two workgroups per CU):
 //   load, wave-striped: wave w owns positions [w * rows * 64, (w + 1) * rows * 64) of the bucket, lane l's i-th register holds
 //                       position w * rows * 64 + i * 64 + l, rows = ceil(size / T); positions past the bucket hold 0xFFFFFFFF
