@@ -70,9 +70,10 @@ __device__ __forceinline__ void sort_bucket(const LocalSortParams& p, const uint
     uint32_t key[K], rank[K], val[PAIRS ? K : 1];
 #pragma unroll
     for (int i = 0; i < K; i++) {
+        key[i] = 0xFFFFFFFFu;   // rows past the bucket's last are never ranked or stored; the paired scatter below looks at one
         if ((uint32_t)i < rows) {
             const uint32_t pos = wbase + (uint32_t)i * 64u;
-            key[i] = pos < size ? bucket[pos] : 0xFFFFFFFFu;
+            if (pos < size) key[i] = bucket[pos];
             if (PAIRS) val[i] = pos < size ? bucket_vals[pos] : 0u;
         }
     }
@@ -119,13 +120,23 @@ __device__ __forceinline__ void sort_bucket(const LocalSortParams& p, const uint
             for (int w = 0; w < W; w++) s_cnt16[w * kLocalMaxBins + tid] = (uint16_t)(local_off + wave_excl[w]);
         }
         __syncthreads();
+        // two rows per uniform branch: both base reads are in flight before the first write waits for its own (0.590 -> 0.584 ms per
+        // 2^28 keys).  A row past the bucket's last reads a counter it never uses -- its key register holds whatever it holds,
+        // masked into the table.
+        static_assert(K % 2 == 0, "rows are scattered in pairs");
 #pragma unroll
-        for (int i = 0; i < K; i++) {
+        for (int i = 0; i < K; i += 2) {
             if ((uint32_t)i < rows) {
-                const uint32_t d = (key[i] >> shift) & mask;
-                const uint32_t pos = (uint32_t)s_cnt16[wave * kLocalMaxBins + d] + rank[i];
-                if (PAIRS) rank[i] = pos;   // the payload's slot
-                s_keys[pos] = key[i];
+                const uint32_t b0 = s_cnt16[wave * kLocalMaxBins + ((key[i] >> shift) & mask)];
+                const uint32_t b1 = s_cnt16[wave * kLocalMaxBins + ((key[i + 1] >> shift) & mask)];
+                const uint32_t pos0 = b0 + rank[i];
+                if (PAIRS) rank[i] = pos0;   // the payload's slot
+                s_keys[pos0] = key[i];
+                if ((uint32_t)(i + 1) < rows) {
+                    const uint32_t pos1 = b1 + rank[i + 1];
+                    if (PAIRS) rank[i + 1] = pos1;
+                    s_keys[pos1] = key[i + 1];
+                }
             }
         }
         __syncthreads();
