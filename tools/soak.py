@@ -17,7 +17,7 @@ while time.time() - t0 < budget_s and done < 200000:
     lg = rng.integers(lo_lg, hi_lg + 1)
     n = int(rng.integers(1 << max(lg - 1, 0), (1 << lg) + 1))
     r = int(rng.choice([8, 8, 8, 4, 4, 2, 1])) if n <= (1 << 20) else int(rng.choice([8, 8, 4]))
-    kind = int(rng.integers(0, 7))
+    kind = int(rng.integers(0, 9))
     s = streams[done % 2]
     with torch.cuda.stream(s):
         k = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda", generator=gen)
@@ -40,6 +40,28 @@ while time.time() - t0 < budget_s and done < 200000:
             lsd.GPULSDRadixSort(k, r, d_vals=v, workspace=ws, stream=s)
             assert torch.equal(v.to(torch.int64), ref.indices), (done, n, r, "pairs")
             assert torch.equal(k.to(torch.int64) & 0xFFFFFFFF, ref.values), (done, n, r, "pairs keys")
+        elif kind == 7 and r >= 4:   # a shard: keys that share their top t bits, sorted with and (every other time) against the hint
+            t = int(rng.integers(1, 9))
+            k = (((k.to(torch.int64) & 0xFFFFFFFF) >> t) | (int(rng.integers(0, 1 << t)) << (32 - t)))
+            k = ((k + (1 << 31)) % (1 << 32) - (1 << 31)).to(torch.int32)
+            if done % 4 == 3 and n > 2:
+                k[n // 2] ^= -(1 << 31)                      # one key outside the prefix: the device must notice
+            ref = torch.sort(k.to(torch.int64) & 0xFFFFFFFF).values
+            st = lsd.lib().lsdsort_u32_device_prefixed(k.data_ptr(), ws.data_ptr(), ws.numel(), n, r, t, s.cuda_stream)
+            assert st == 0, (done, n, r, t, st)
+            assert torch.equal(k.to(torch.int64) & 0xFFFFFFFF, ref), (done, n, r, "prefixed", t)
+        elif kind == 8 and r >= 4:   # two or three payload arrays
+            np_ = int(rng.integers(2, 4))
+            ws = torch.empty(max(int(lsd.lib().lsdsort_workspace_bytes(n, r, np_)), 256), dtype=torch.uint8, device="cuda")
+            idx = torch.arange(n, dtype=torch.int32, device="cuda")
+            pay = [(idx * (2 * e + 3) + e).to(torch.int32) for e in range(np_)]
+            k &= int(rng.integers(0, 1 << 31)) | 0xFF          # duplicates: stability matters
+            ref = torch.sort((k.to(torch.int64) & 0xFFFFFFFF), stable=True)
+            want = [p_[ref.indices] for p_ in pay]
+            lsd.GPUSortMulti(k, pay, r=r, workspace=ws, stream=s)
+            assert torch.equal(k.to(torch.int64) & 0xFFFFFFFF, ref.values), (done, n, r, "multi keys")
+            for e in range(np_):
+                assert torch.equal(pay[e], want[e]), (done, n, r, "multi payload", e)
         elif kind == 4 and r >= 4:
             ref = torch.sort(k, descending=bool(done & 1)).values
             lsd.GPUSortTyped(k, "int32", bool(done & 1), r=r, workspace=ws, stream=s)
