@@ -275,13 +275,13 @@ std::atomic<int> g_rank_setting{-1};   // -1 auto, 0 mask forms only, 2 returnin
 // [pass][digit][region] count table), i.e. tables that do not describe the keys -- what a miscounting stage-1 variant
 // produces.  tests/test_fault_path.py drives the destination guard with it, once.
 struct CorruptCounts {
-    uint32_t from = 0, to = 0, delta = 0, keep_sum = 1;
+    uint32_t from = 0, to = 0, delta = 0, keep_sum = 1;   // keep_sum bit 1: the words are the HYBRID form's count fields
 };
 std::mutex g_corrupt_mutex;
 CorruptCounts g_corrupt;
 __global__ void corrupt_counts_kernel(uint32_t* counts, CorruptCounts c)
 {
-    if (c.keep_sum) counts[c.from] -= c.delta;
+    if (c.keep_sum & 1u) counts[c.from] -= c.delta;
     counts[c.to] += c.delta;
 }
 #endif
@@ -449,6 +449,19 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             LSD_HIP(lsd::launch_hybrid_plan(radix_bits, bucket, (uint32_t)n, bb, bases, radix_bits == 8 ? fields + 2048 : fields, joint, hyb,
                                             bases + lsd::kHybridBuckets + 1,
                                             (uint32_t)hybrid_small_cap(n, pairs), stream));
+#ifdef LSD_FAULT_INJECT
+            {   // diagnostic build only: the hybrid form's own fields falsified behind the planner (its verdict stands)
+                CorruptCounts c;
+                {
+                    std::lock_guard<std::mutex> lock(g_corrupt_mutex);
+                    c = g_corrupt;
+                }
+                if (c.delta && (c.keep_sum & 2u)) {
+                    hipLaunchKernelGGL(corrupt_counts_kernel, dim3(1), dim3(1), 0, stream, fields, c);
+                    LSD_HIP(hipGetLastError());
+                }
+            }
+#endif
             // the global passes' region tables: the first one's regions are by position (like any first pass), the others' by the
             // top bits of the digit before -- exactly what stage 2 builds for consecutive passes
             // (no fault word: where the sample or the planner has said no these counts are partial or absent, and nobody uses the tables)
@@ -489,7 +502,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
                 std::lock_guard<std::mutex> lock(g_corrupt_mutex);
                 c = g_corrupt;
             }
-            if (c.delta) {
+            if (c.delta && !(c.keep_sum & 2u)) {
                 hipLaunchKernelGGL(corrupt_counts_kernel, dim3(1), dim3(1), 0, stream, counts, c);
                 LSD_HIP(hipGetLastError());
             }

@@ -61,7 +61,7 @@ if mode == "wide":
     print(json.dumps(out), flush=True)
     sys.exit(0)
 r = 8
-n = (1 << 23) + 123
+n = (1 << 23) + 123 if mode != "hybrid_counts" else (1 << 26) + 123     # hybrid_counts: a size where the hybrid form runs
 GUARD = 1 << 16                     # int32 words on either side of the keys / bytes on either side of the workspace
 SENT = 0x7E7E7E7E
 rng = np.random.default_rng(5)
@@ -105,6 +105,11 @@ else:
     word = lambda p, d, x: (p * 256 + d) * 8 + x
     if mode == "counts_sum":
         raw.lsdsort_debug_corrupt_counts(0, word(0, 0, 0), 5, 0)
+    elif mode == "hybrid_counts":
+        # the same falsification in the hybrid form's second global pass (field B = the second of its [pass][digit][region]
+        # fields; keep_sum bit 1 selects them): the planner has said yes from the bucket counts, the pass's tables are wrong,
+        # its destination guard must refuse the stores that would land behind the output
+        raw.lsdsort_debug_corrupt_counts(word(1, 255, 7), word(1, 0, 0), 1000, 3)
     else:
         raw.lsdsort_debug_corrupt_counts(word(3, 255, 7), word(3, 0, 0), 1000, 1)
 torch.cuda.synchronize()

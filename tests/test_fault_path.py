@@ -72,6 +72,25 @@ def test_inconsistent_counts_never_store_out_of_bounds(mode):
 
 
 @pytest.mark.gpu
+def test_inconsistent_hybrid_fields_never_store_out_of_bounds():
+    """The hybrid form's global passes run from count fields of their own (hybrid.hip).  Falsified behind the planner
+    (sum kept, 1000 keys booked on the wrong digit of the second pass), the pass kernel's destination guard must turn them into
+    LSDSORT_ERR_DEVICE_FAULT with the guard zones around keys and workspace intact; the next sort in the workspace is clean."""
+    assert os.path.exists(FAULT_LIB), "build the diagnostic library first: make -C lsdradixsort_amd/csrc faultinject"
+    env = dict(os.environ, LSDSORT_LIB=FAULT_LIB)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_fault_worker.py"), "hybrid_counts"], env=env, capture_output=True,
+                       text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["launch_status"] == 0
+    assert out["check_status"] == -7, out
+    assert out["guards_intact_after_fault"], "stores left the buffers on inconsistent hybrid fields"
+    assert out["second_status"] == 0 and out["second_check"] == 0, out
+    assert out["second_sorted"]
+    assert out["guards_intact_after_clean_sort"]
+
+
+@pytest.mark.gpu
 def test_wide_sort_keeps_the_first_inner_sorts_fault():
     """lsdsort_u64_device = two key/value sorts sharing one workspace; the second one's opening memset clears the fault word
     (ADVICE r2).  A bounded-wait give-up in the FIRST inner sort only must still come out of lsdsort_wide_check_device
