@@ -382,9 +382,10 @@ LSDSORT_API int lsdsort_set_xcd_chunk(int chunk);
  * sorts and 1-bit digits always run every pass.  0 switches it off (every pass runs, as the reference's do). */
 LSDSORT_API int lsdsort_set_pass_skipping(int on);
 /* The hybrid form (lsdradixsort_amd/csrc/hybrid.hip, local_sort.hip; no reference counterpart -- its every pass goes through
- * global memory, .cu:844-905).  Sorts of 2^26 .. 4.8e8 keys or key/value pairs (uint32, int32, float32, either order) with 8- or
+ * global memory, .cu:844-905).  Sorts of 2^26 .. 9.6e8 keys or key/value pairs (uint32, int32, float32, either order) with 8- or
  * 4-bit digits: bits 16-31 are sorted first by ordinary global passes (LSD order; two passes at 8-bit digits, four at 4-bit),
- * which leaves the array sorted by its top 16 bits; every bucket of equal top-15-bit value (top 14 bits while uniform keys still fit the local stage: up to about 2^27 items) is
+ * which leaves the array sorted by its top 16 bits; every bucket of equal top-15-bit value (top 14 bits while uniform keys still fit the local stage: up to about 2^27 items; top 16
+ * from 4.8e8) is
  * then finished inside one CU's LDS (bits 0-8, then 9-16) and stored once: at 8-bit digits 4 + 8 + 8 + 8 = 28 bytes per key of
  * memory traffic instead of 4 + 4 x 8 = 36 (pairs: 52 instead of 68), at 4-bit digits 44 instead of 68.  Valid only if every
  * bucket fits the local stage (16384 keys), which depends on the keys: the upfront read counts the buckets exactly and the

@@ -1,4 +1,4 @@
-// hybrid.hip -- stage 1 and the planner of the HYBRID form (2^26 .. 4.8e8 items; 8- or 4-bit digits; keys, pairs, records; typed keys).
+// hybrid.hip -- stage 1 and the planner of the HYBRID form (2^26 .. 9.6e8 items; 8- or 4-bit digits; keys, pairs, records; typed keys).
 // Written below for its first shape -- 8-bit digits, 2^15 buckets; what differs at 4-bit digits, with 2^14 buckets, for typed keys
 // and for shards that share a key prefix is said at the kernels.
 //
@@ -39,24 +39,26 @@ constexpr int kHybridVpt = 4;              // 16-byte vectors per thread per gro
 __global__ void __launch_bounds__(1024) hybrid_sample_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t bucket_shift,
                                                              uint32_t* __restrict__ hopeless, uint32_t prefix)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];   // [kHybridBuckets]
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];   // [2^15 at most: with 2^16 buckets two neighbours share a counter]
     constexpr uint32_t kSamples = 65536;
     const unsigned long long step = n / kSamples;   // n >= 2^26: at least 1024
     const uint32_t tid = threadIdx.x;
     // interleaved: workgroup w takes samples w, w + 64, ... so each sees the WHOLE array at 64 x step -- a contiguous run of one
     // bucket's keys (sorted input, a bucket of 11000 keys stored together) is spread over the workgroups instead of filling one
     const uint32_t k = keys[(size_t)((unsigned long long)(tid * 64u + blockIdx.x) * step)];
-    for (uint32_t j = tid; j < (1u << (32u - bucket_shift)); j += 1024) s_cnt[j] = 0;
+    const uint32_t fold = bucket_shift < 17u ? 17u - bucket_shift : 0u;
+    const uint32_t counters = 1u << (32u - bucket_shift - fold);
+    for (uint32_t j = tid; j < counters; j += 1024) s_cnt[j] = 0;
     __syncthreads();
     const uint32_t mask = (1u << (32u - bucket_shift)) - 1u;
-    if (atomicAdd(&s_cnt[(k >> (bucket_shift - prefix)) & mask], 1u) + 1u >= 8u) *hopeless = 1u;
+    if (atomicAdd(&s_cnt[((k >> (bucket_shift - prefix)) & mask) >> fold], 1u) + 1u >= 8u) *hopeless = 1u;
 }
 
 hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bits, uint32_t* hopeless, hipStream_t stream, int prefix)
 {
     if (n < 65536u * 64u || bucket_bits < 11 || (1 << bucket_bits) > kHybridBuckets || prefix < 0 || prefix > 8) return hipErrorInvalidValue;
     const uint32_t bucket_shift = 32u - (uint32_t)bucket_bits;
-    constexpr size_t lds_bytes = (size_t)kHybridBuckets * sizeof(uint32_t);
+    constexpr size_t lds_bytes = (size_t)32768 * sizeof(uint32_t);
     static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_sample_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (attr != hipSuccess) return attr;
@@ -66,7 +68,10 @@ hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bit
 
 // R: digit width of the global passes, 8 or 4.  XF: the general instance -- typed keys, counted as to_sortable(key, xf) (the
 // identity when xf is off), and / or a key prefix: buckets and digits taken `prefix` bits lower, every key checked against the first
-template <int R, bool XF>
+// B16: 2^16 buckets, counted in 16-bit halves of the same 32768 LDS words.  A half that overflows (65536 keys of one bucket in one
+// workgroup's share: nothing the local stage could take anyway) wraps or carries into its neighbour; either way the counts then
+// sum to LESS than n (every such event loses 65535 or 65536), which the planner's sum check refuses.
+template <int R, bool XF, bool B16>
 __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                                uint32_t region0_keys, uint32_t* __restrict__ field_a,
                                                                                uint32_t* __restrict__ bucket, uint32_t vec_chunks,
@@ -82,9 +87,9 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
     const uint32_t NB = 1u << (32u - bucket_shift);   // at most kHybridBuckets (the LDS is sized for that)
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     uint32_t* const s_a = s_mem;                 // [region][digit][CA], region-major: a wave's lanes share the region
-    uint32_t* const s_b = s_mem + FA * CA;       // [NB]
+    uint32_t* const s_b = s_mem + FA * CA;       // [NB] words, or (B16) [NB / 2] words of two 16-bit counters
     const uint32_t tid = threadIdx.x, lane = tid & 63u, copy = tid & (CA - 1);
-    for (uint32_t j = tid; j < FA * CA + NB; j += T) s_mem[j] = 0;
+    for (uint32_t j = tid; j < FA * CA + (B16 ? NB / 2u : NB); j += T) s_mem[j] = 0;
     __syncthreads();
 
     const uint32_t a_shift = XF ? 16u - prefix : 16u, b_shift = XF ? bucket_shift - prefix : bucket_shift, b_mask = NB - 1u;
@@ -92,9 +97,13 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
     auto slot_b = [&](uint32_t k) -> uint32_t { return XF ? (k >> b_shift) & b_mask : k >> bucket_shift; };
     const uint32_t kref = XF && n ? to_sortable(keys[0], xf) : 0u;
     uint32_t differs = 0;   // XF: OR of (key ^ first key) over this thread's keys -- the prefix check
+    auto add_b = [&](uint32_t b, uint32_t count) {   // bucket b += count
+        if (B16) atomicAdd(&s_b[b >> 1], count << ((b & 1u) << 4));
+        else atomicAdd(&s_b[b], count);
+    };
     auto count_plain = [&](uint32_t k, uint32_t region0) {
         atomicAdd(&s_a[slot_a(k, region0) + copy], 1u);
-        atomicAdd(&s_b[slot_b(k)], 1u);
+        add_b(slot_b(k), 1u);
     };
     uint32_t key1 = 0, key2 = 0;   // sticky heavy-key candidates (uniform)
     bool have1 = false, have2 = false;
@@ -144,11 +153,11 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
                 if (lane == 0) {
                     if (n1) {
                         atomicAdd(&s_a[slot_a(key1, region0)], n1);
-                        atomicAdd(&s_b[slot_b(key1)], n1);
+                        add_b(slot_b(key1), n1);
                     }
                     if (n2) {
                         atomicAdd(&s_a[slot_a(key2, region0)], n2);
-                        atomicAdd(&s_b[slot_b(key2)], n2);
+                        add_b(slot_b(key2), n2);
                     }
                 }
                 continue;
@@ -181,12 +190,12 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
                         const uint32_t sb = slot_b(k4[q]);
                         const bool h = sb == b_first;
                         held += (uint32_t)__builtin_popcountll(__ballot(h));
-                        if (!h) atomicAdd(&s_b[sb], 1u);
+                        if (!h) add_b(sb, 1u);
                     }
-                    if (lane == 0) atomicAdd(&s_b[b_first], held);
+                    if (lane == 0) add_b(b_first, held);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) atomicAdd(&s_b[slot_b(k4[q])], 1u);
+                    for (int q = 0; q < 4; q++) add_b(slot_b(k4[q]), 1u);
                 }
             }
         }
@@ -242,7 +251,7 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
         if (cnt) atomicAdd(&field_a[j], cnt);
     }
     for (uint32_t j = tid; j < NB; j += T) {
-        const uint32_t cnt = s_b[j];
+        const uint32_t cnt = B16 ? (s_b[j >> 1] >> ((j & 1u) << 4)) & 0xFFFFu : s_b[j];
         if (cnt) atomicAdd(&bucket[j], cnt);
     }
 }
@@ -253,13 +262,15 @@ hipError_t launch_hybrid_histograms(int radix_bits, const uint32_t* keys, uint32
     if (prefix < 0 || prefix > 8 || (prefix > 0 && !violated)) return hipErrorInvalidValue;
     if (bucket_bits < 11 || (1 << bucket_bits) > kHybridBuckets || (radix_bits != 8 && radix_bits != 4)) return hipErrorInvalidValue;
     constexpr int T = kHybridHistThreads;
-    constexpr size_t lds_bytes = (size_t)(4096 + kHybridBuckets) * sizeof(uint32_t);
+    constexpr size_t lds_bytes = (size_t)(4096 + 32768) * sizeof(uint32_t);   // 2^15 bucket counters of 32 bits or 2^16 of 16
     static_assert(2048 * kHybridCopiesA == 4096, "both digit widths keep 4096 field counters");
     static_assert(lds_bytes <= 160 * 1024, "one workgroup per CU");
     if (region0_keys == 0 || region0_keys % (T * 4) != 0) return hipErrorInvalidValue;
     static hipError_t attr = [] {
-        const void* kernels[4] = {reinterpret_cast<const void*>(hybrid_histograms_kernel<8, false>), reinterpret_cast<const void*>(hybrid_histograms_kernel<8, true>),
-                                  reinterpret_cast<const void*>(hybrid_histograms_kernel<4, false>), reinterpret_cast<const void*>(hybrid_histograms_kernel<4, true>)};
+#define LSD_K(R, XF, B16) reinterpret_cast<const void*>(hybrid_histograms_kernel<R, XF, B16>)
+        const void* kernels[8] = {LSD_K(8, false, false), LSD_K(8, true, false), LSD_K(4, false, false), LSD_K(4, true, false),
+                                  LSD_K(8, false, true),  LSD_K(8, true, true),  LSD_K(4, false, true),  LSD_K(4, true, true)};
+#undef LSD_K
         for (const void* k : kernels) {
             const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e != hipSuccess) return e;
@@ -273,12 +284,14 @@ hipError_t launch_hybrid_histograms(int radix_bits, const uint32_t* keys, uint32
     uint32_t blocks = aligned ? (vec_chunks + kHybridVpt - 1) / kHybridVpt : (n + T * 16 - 1) / (T * 16);
     if (blocks > 256) blocks = 256;
     if (blocks == 0) blocks = 1;
-#define LSD_HYB_HIST(R, XF) hipLaunchKernelGGL((hybrid_histograms_kernel<R, XF>), dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks, skip, 32u - (uint32_t)bucket_bits, xf, (uint32_t)prefix, violated)
-    const bool general = xf.on || prefix > 0;
+#define LSD_HYB_HIST(R, XF, B16) hipLaunchKernelGGL((hybrid_histograms_kernel<R, XF, B16>), dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks, skip, 32u - (uint32_t)bucket_bits, xf, (uint32_t)prefix, violated)
+    const bool general = xf.on || prefix > 0, b16 = bucket_bits == 16;
     if (radix_bits == 8) {
-        if (general) LSD_HYB_HIST(8, true); else LSD_HYB_HIST(8, false);
+        if (b16) { if (general) LSD_HYB_HIST(8, true, true); else LSD_HYB_HIST(8, false, true); }
+        else     { if (general) LSD_HYB_HIST(8, true, false); else LSD_HYB_HIST(8, false, false); }
     } else {
-        if (general) LSD_HYB_HIST(4, true); else LSD_HYB_HIST(4, false);
+        if (b16) { if (general) LSD_HYB_HIST(4, true, true); else LSD_HYB_HIST(4, false, true); }
+        else     { if (general) LSD_HYB_HIST(4, true, false); else LSD_HYB_HIST(4, false, false); }
     }
 #undef LSD_HYB_HIST
     return hipGetLastError();
@@ -292,7 +305,7 @@ hipError_t launch_hybrid_histograms(int radix_bits, const uint32_t* keys, uint32
 //   4-bit digits: all four ([pass][digit][region], region = the previous pass's digit): D (bits 28-31 by 24-27) and C (bits 24-27
 //                 by 20-23) are sums of buckets, B (bits 20-23 by 16-19) and A (bits 16-19 by position region) sums of the joint
 //                 field [position region][bits 16-23] of the upfront read.
-template <int R, int PER>   // PER = consecutive buckets per thread: 32 for 2^15 buckets, 16 for 2^14 (a thread = the top ten bits)
+template <int R, int PER>   // PER = consecutive buckets per thread: 64 / 32 / 16 for 2^16 / 2^15 / 2^14 buckets (a thread = the top ten bits)
 __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __restrict__ bucket, uint32_t n, uint32_t* __restrict__ bases,
                                                            uint32_t* __restrict__ fields_out, const uint32_t* __restrict__ joint,
                                                            uint32_t* __restrict__ words, uint32_t* __restrict__ large_list, uint32_t small_cap)
@@ -390,7 +403,9 @@ hipError_t launch_hybrid_plan(int radix_bits, const uint32_t* bucket, uint32_t n
 {
     if ((radix_bits != 8 && radix_bits != 4) || (radix_bits == 4 && !joint)) return hipErrorInvalidValue;
 #define LSD_PLAN(R, PER) hipLaunchKernelGGL((hybrid_plan_kernel<R, PER>), dim3(1), dim3(1024), 0, stream, bucket, n, bases, fields_out, joint, words, large_list, small_cap)
-    if (bucket_bits == 15) {
+    if (bucket_bits == 16) {
+        if (radix_bits == 8) LSD_PLAN(8, 64); else LSD_PLAN(4, 64);
+    } else if (bucket_bits == 15) {
         if (radix_bits == 8) LSD_PLAN(8, 32); else LSD_PLAN(4, 32);
     } else if (bucket_bits == 14) {
         if (radix_bits == 8) LSD_PLAN(8, 16); else LSD_PLAN(4, 16);

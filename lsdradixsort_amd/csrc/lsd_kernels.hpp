@@ -224,16 +224,19 @@ hipError_t launch_local_sort(const LocalSortParams& p, hipStream_t stream);
 
 // ---- the hybrid form's upfront read and planner (hybrid.hip) ------------------------------------------------------------
 // A bucket = the keys that agree on their top `bucket_bits` bits: 14 while what uniform keys put into one of 2^14 buckets (mean
-// + 6 sigma) fits the three-per-CU variant of the local stage (10240 keys, 8192 pairs), 15 above.  Larger buckets are cheaper per
-// key (a bucket's scans, barriers and its unoverlapped first load and last store are per bucket: 2^27 keys in buckets of 4096 cost
-// the local stage 0.35-0.39 ms, in buckets of 8192 0.29).  Every table is sized for 2^15.
-constexpr int kHybridBuckets = 1 << 15;
+// + 6 sigma) fits the three-per-CU variant of the local stage (10240 keys, 8192 pairs), 15 up to an average of 14648 keys a
+// bucket (4.8e8 items), 16 above (to 9.6e8 items).  Larger buckets are cheaper per key (a bucket's scans, barriers and its
+// unoverlapped first load and last store are per bucket: 2^27 keys in buckets of 4096 cost the local stage 0.35-0.39 ms, in
+// buckets of 8192 0.29).  Every table is sized for 2^16.
+constexpr int kHybridBuckets = 1 << 16;
+constexpr size_t kHybridMaxMeanBucket = 14648;   // above, the largest bucket of even uniform keys nears the 16384-key capacity
 constexpr int hybrid_bucket_bits(size_t n, bool pairs)
 {
     const size_t mean = n >> 14, cap = pairs ? 8192 : 10240;
     size_t root = 1;                               // ceil(sqrt(mean)), no <cmath> in device headers
     while (root * root < mean) root++;
-    return mean + 6 * root <= cap ? 14 : 15;
+    if (mean + 6 * root <= cap) return 14;
+    return (n >> 15) <= kHybridMaxMeanBucket ? 15 : 16;
 }
 // plan words (uint32, in the workspace's control block): written by the planner, read by every kernel of either form
 constexpr int kHybridWordOk = 0;          // 1: the hybrid form runs (the ordinary form's kernels return at once)

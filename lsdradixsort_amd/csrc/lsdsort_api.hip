@@ -49,11 +49,11 @@ std::atomic<int> g_hybrid{[] {                                          // lsdso
     return (e && e[0] == '0') ? 0 : 1;
 }()};
 // The hybrid form is tried for 8-bit-digit sorts whose AVERAGE bucket (top 15 bits from 2^27 keys, top 14 below) leaves the local
-// stage room: 4096 .. 14648 keys per bucket (below, tens of thousands of workgroups of almost nothing cost more than the two passes
+// stage room: 4096 .. 14648 keys per bucket, 2^14 .. 2^16 buckets (below, tens of thousands of workgroups of almost nothing cost more than the two passes
 // they replace; above, the largest bucket of even uniform keys nears the 16384-key capacity).  Whether it RUNS is decided on the
 // device from the exact bucket counts.
 constexpr size_t kHybridMinKeys = (size_t)1 << 26;
-constexpr size_t kHybridMaxKeys = (size_t)480 * 1000 * 1000;
+constexpr size_t kHybridMaxKeys = (size_t)960 * 1000 * 1000;
 // The capacity of the local stage's launch over all buckets: the smallest variant that holds what uniform keys put into a bucket
 // (mean + 6 sigma); larger buckets go on the planner's list for the 16384-key variant.
 int hybrid_small_cap(size_t n, bool pairs)
@@ -422,7 +422,8 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     // never skips a pass.
     const bool try_hybrid = algorithm == LSDSORT_ALGO_ONESWEEP && (radix_bits == 8 || radix_bits == 4) && !feed &&
                             rank_method == lsd::kRankLdsAdd && n >= kHybridMinKeys && n <= kHybridMaxKeys &&
-                            (n >> lsd::hybrid_bucket_bits(n, pairs)) <= 14648 && shape->tile() == 32768 && g_hybrid.load(std::memory_order_relaxed);
+                            (n >> lsd::hybrid_bucket_bits(n, pairs)) <= lsd::kHybridMaxMeanBucket && shape->tile() == 32768 &&
+                            g_hybrid.load(std::memory_order_relaxed);
     uint32_t* plan = nullptr;
     if (algorithm == LSDSORT_ALGO_ONESWEEP && (!xf.on || try_hybrid) && 2 * passes + 1 <= lsd::kPlanWords &&
         g_skip_dead_passes.load(std::memory_order_relaxed))
@@ -551,8 +552,8 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             const int bb = lsd::hybrid_bucket_bits(n, pairs);
             lp.num_buckets = 1u << bb;
             const int low_bits = 32 - prefix - bb;   // the 17 (18) bits below a bucket's own, fewer under a prefix: bits 0-8, then the rest
-            lp.shift[0] = 0; lp.width[0] = 9;
-            lp.shift[1] = 9; lp.width[1] = (uint32_t)(low_bits - 9);
+            lp.shift[0] = 0; lp.width[0] = (uint32_t)(low_bits < 9 ? low_bits : 9);
+            lp.shift[1] = lp.width[0]; lp.width[1] = (uint32_t)low_bits - lp.width[0];   // 0: one digit pass
             lp.skip = hyb + lsd::kHybridWordSkipLocal;
             lp.xout = xf;
             lp.fault = control;

@@ -58,13 +58,14 @@ def test_local_stage_alone(gpu):
                     assert np.array_equal(got_v[lo:hi], vals[lo:hi][order]), (low_bits, b, size, "payload order = stable order")
 
 
-@pytest.mark.parametrize("log2n,extra,radix", [(26, 999, 8), (27, 0, 8), (27, 12345, 8), (28, 777, 8), (26, 4097, 4), (27, 31, 4), (28, 5, 4)])
+@pytest.mark.parametrize("log2n,extra,radix", [(26, 999, 8), (27, 0, 8), (27, 12345, 8), (28, 777, 8), (29, 4242, 8), (26, 4097, 4), (27, 31, 4), (28, 5, 4),
+                                               (29, 11, 4)])
 def test_hybrid_equals_torch_sort_and_the_four_pass_form(gpu, log2n, extra, radix):
     """radix 8: two global passes; radix 4 (BASELINE configs[1]'s digit width): four, their count fields derived by the planner."""
     import torch
 
     n = (1 << log2n) + extra
-    bb = 15 if log2n >= 28 else 14          # bucket = the top bb bits (lsd_kernels.hpp hybrid_bucket_bits: keys, 2^26 .. 2^27 -> 14)
+    bb = {26: 14, 27: 14, 28: 15, 29: 16}[log2n]   # bucket = the top bb bits (lsd_kernels.hpp hybrid_bucket_bits, keys)
     sh, low = 32 - bb, (1 << (32 - bb)) - 1
     gen = torch.Generator(device="cuda")
     gen.manual_seed(4000 + log2n + extra)
