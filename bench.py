@@ -703,10 +703,12 @@ def main(argv=None):
             total_txt = f"2^{(n * world).bit_length() - 1} keys over {world} GPU{'s' if world > 1 else ''}" if (n * world) & (n * world - 1) == 0 else f"{n * world} keys"
             workload = (f"{total_txt} = 2^{log2_keys} uniform uint32 keys per GPU (mt19937 seed=rank), "
                         f"{'MSB-bucket' if args.partition == 'msb' else 'sampled-splitter'} partition + {'grouped ncclSend/ncclRecv (C++ step, lsdsort_sharded_u32_device_ex)' if exchange_path == 'c++' else 'torch.distributed all-to-all'} over xGMI + "
-                        f"local {r}-bit LSD sort ({passes} passes) per step"
+                        f"local {r}-bit LSD sort per step (a shard of this size alone: "
+                        + (f"hybrid form, {16 // r} global passes + LDS-resident local stage" if stage_ms and stage_ms.get("hybrid_form") else f"{passes} global passes")
+                        + "; the step's sort plans below the shard's key prefix)"
                         + (" [BASELINE configs[3]]" if n * world == 1 << 30 and world == 8 else ""))
         else:
-            form = (", hybrid form (digits 2 and 3 by two global passes, digits 0 and 1 inside each CU's LDS; decided on the device)"
+            form = (f", hybrid form (bits 16-31 by {16 // r} global passes, the low bits inside each CU's LDS; decided on the device)"
                     if stage_ms and stage_ms.get("hybrid_form") else f", {passes} global passes")
             workload = (f"2^{log2_keys} uniform uint32 {'key+payload pairs' if args.pairs else 'keys'} per GPU "
                         f"(mt19937 seed=rank), {r}-bit radix{form}, {args.algorithm}, device-resident")
