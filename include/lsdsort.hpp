@@ -76,6 +76,21 @@ inline void sort_device_descending(uint32_t* d_keys, void* d_workspace, size_t w
           "lsdsort_keys_device");
 }
 
+// A shard of a range-partitioned array: keys expected to share their top `common_prefix_bits` bits (a hint; the device checks)
+inline void sort_shard_device(uint32_t* d_keys, void* d_workspace, size_t workspace_bytes_, size_t n, int common_prefix_bits,
+                              int radix_bits = 8, void* hip_stream = nullptr)
+{
+    check(lsdsort_u32_device_prefixed(d_keys, d_workspace, workspace_bytes_, n, radix_bits, common_prefix_bits, hip_stream),
+          "lsdsort_u32_device_prefixed");
+}
+// Did the last sort queued in this workspace run the hybrid form (lsdsort_set_hybrid)?  Synchronises the stream.
+inline bool ran_hybrid_form(const void* d_workspace, void* hip_stream = nullptr)
+{
+    int hybrid = 0;
+    check(lsdsort_workspace_form(d_workspace, hip_stream, &hybrid), "lsdsort_workspace_form");
+    return hybrid != 0;
+}
+
 // One rank of a multi-GPU sort (one process per GPU): RAII over lsdsort_comm_*.  Rank 0 calls unique_id() and ships
 // the 128 bytes to the other ranks over the launcher's own channel (MPI_Bcast, a file, torch.distributed).
 struct comm_id {
