@@ -393,6 +393,11 @@ LSDSORT_API int lsdsort_set_pass_skipping(int on);
  * 10 % for the attempt, 1 % where a 65536-key sample already shows it).  Same result either way.  On by default; 0 = always
  * the ordinary passes, the reference's structure. */
 LSDSORT_API int lsdsort_set_hybrid(int on);
+/* Sorts of up to 16384 keys or pairs (uint32, default algorithm and rank form) are ONE launch: one workgroup sorts them inside
+ * its LDS in four 8-bit digit passes (lsdradixsort_amd/csrc/local_sort.hip) instead of clear + stage 1 + stage 2 + 32 / r passes,
+ * whose own latencies are all there is at this size (12 us instead of 39).  Same result.  On by default; 0 = the chained form at
+ * every size (the reference's stage structure). */
+LSDSORT_API int lsdsort_set_small_sort(int on);
 /* Which form the last sort queued on `hip_stream` in this workspace ran: *hybrid = 1 the hybrid form, 0 the ordinary passes (also
  * where the hybrid form was not tried).  Reads the device's verdict back: synchronises the stream. */
 LSDSORT_API int lsdsort_workspace_form(const void* d_workspace, void* hip_stream, int* hybrid);

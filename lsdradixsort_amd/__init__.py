@@ -8,7 +8,7 @@ library, or without a gfx950 device, every entry raises.
 from .errors import (LSDSORT_ALGO_ONESWEEP, LSDSORT_ALGO_STAGED, LSDSORT_MAX_KEYS, LsdsortError)  # noqa: F401
 from ._lib import LIB_PATH, lib  # noqa: F401
 from .api import (BuildHistograms, BuildOffsets, DigitHistograms, GPULSDRadixSort, GPULSDRadixSortTimed, GPUSortMulti, GPUSortTyped, GPUSortWide,  # noqa: F401
-                  MSBPartition, RankScatter, SplitterPartition, ThresholdPartition, sharded_thresholds, alloc_workspace, rank_method, set_hybrid, set_pass_skipping, workspace_form, set_rank_method, set_tile_config, set_xcd_chunk, sort,
+                  MSBPartition, RankScatter, SplitterPartition, ThresholdPartition, sharded_thresholds, alloc_workspace, rank_method, set_hybrid, set_pass_skipping, set_small_sort, workspace_form, set_rank_method, set_tile_config, set_xcd_chunk, sort,
                   sort_pairs, tile_keys,
                   to_device, to_host, workspace_bytes)
 

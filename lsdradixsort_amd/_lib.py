@@ -127,6 +127,7 @@ SIGNATURES = {
     "lsdsort_set_xcd_chunk": (c_int, [c_int]),
     "lsdsort_set_pass_skipping": (c_int, [c_int]),
     "lsdsort_set_hybrid": (c_int, [c_int]),
+    "lsdsort_set_small_sort": (c_int, [c_int]),
     "lsdsort_workspace_form": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(c_int)]),
     "lsdsort_u32_device_prefixed": (c_int, [c_u32p, ctypes.c_void_p, c_size, c_size, c_int, c_int, ctypes.c_void_p]),
     "lsdsort_set_rank_method": (c_int, [c_int]),

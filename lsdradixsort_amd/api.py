@@ -120,6 +120,11 @@ def set_hybrid(on: bool) -> None:
     check(lib().lsdsort_set_hybrid(1 if on else 0), "lsdsort_set_hybrid")
 
 
+def set_small_sort(on: bool) -> None:
+    """Sorts of up to 16384 items in one launch (``lsdsort_set_small_sort``).  Default on; off = the chained form at every size."""
+    check(lib().lsdsort_set_small_sort(1 if on else 0), "lsdsort_set_small_sort")
+
+
 def workspace_form(workspace, stream=None) -> int:
     """1 if the last sort queued in ``workspace`` ran the hybrid form, 0 if the ordinary passes (``lsdsort_workspace_form``)."""
     import ctypes

@@ -41,7 +41,8 @@ constexpr size_t local_lds_words() { return (size_t)kLocalThreads * K + kLocalWa
 // of the other launch); uniform keys at 2^28 have buckets of 8192 +- 300.
 // PAIRS: a payload word follows each key (LocalSortParams::vals).  It takes the key's LDS slot in a second round of every pass, as
 // in the global pass kernel: keys to LDS, keys back, payloads to the same slots, payloads back -- two more barriers per pass.
-template <int K, bool PAIRS, bool XOUT>
+// WHOLE: the bucket is the whole array [0, p.num_buckets) and a fourth digit pass may follow (launch_small_sort)
+template <int K, bool PAIRS, bool XOUT, bool WHOLE = false>
 __device__ __forceinline__ void sort_bucket(const LocalSortParams& p, const uint32_t b)
 {
     constexpr int T = kLocalThreads, W = kLocalWaves, HW = kLocalMaxBins / 2;   // HW: counter words per wave
@@ -53,7 +54,7 @@ __device__ __forceinline__ void sort_bucket(const LocalSortParams& p, const uint
     lds_u32* const s_misc = (lds_u32*)(s_cnt + W * HW);
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t lo = p.bases[b], hi = p.bases[b + 1];
+    const uint32_t lo = WHOLE ? 0u : p.bases[b], hi = WHOLE ? p.num_buckets : p.bases[b + 1];
     const uint32_t size = hi - lo;
     if (size == 0u || hi < lo) return;
     if (size > (uint32_t)CAP) {
@@ -178,6 +179,10 @@ __device__ __forceinline__ void sort_bucket(const LocalSortParams& p, const uint
     }
     if (p.width[2]) {
         digit_pass(p.shift[2], p.width[2]);
+        take_out(!WHOLE || p.width[3] == 0u);
+    }
+    if (WHOLE && p.width[2] && p.width[3]) {
+        digit_pass(p.shift[3], p.width[3]);
         take_out(true);
     }
 }
@@ -402,12 +407,49 @@ static hipError_t launch_local_inst_x(const LocalSortParams& p, hipStream_t stre
     return hipGetLastError();
 }
 
+// A sort of up to 16384 items is one workgroup's work: one launch instead of the eight of the chained form (whose kernels are
+// all latency at this size: 39 us for 2^14 keys).
+template <bool PAIRS>
+__global__ void __launch_bounds__(kLocalThreads, (PAIRS ? 2 : 4)) small_sort_kernel(const LocalSortParams p, uint32_t* clear0, uint32_t* clear1)
+{
+    if (threadIdx.x == 0) {
+        if (clear0) *clear0 = 0u;
+        if (clear1) *clear1 = 0u;
+    }
+    sort_bucket<32, PAIRS, false, true>(p, 0u);
+}
+
+hipError_t launch_small_sort(uint32_t* keys, uint32_t* vals, uint32_t n, uint32_t* clear0, uint32_t* clear1, hipStream_t stream)
+{
+    if (!keys || n == 0 || n > (uint32_t)kLocalSortCap) return hipErrorInvalidValue;
+    LocalSortParams p{};
+    p.keys = keys;
+    p.vals = vals;
+    p.num_buckets = n;                                  // WHOLE: the array's length
+    for (int i = 0; i < 4; i++) {
+        p.shift[i] = 8u * (uint32_t)i;
+        p.width[i] = 8u;
+    }
+    constexpr size_t lds_bytes = local_lds_words<32>() * sizeof(uint32_t);
+    if (vals) {
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(small_sort_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (attr != hipSuccess) return attr;
+        hipLaunchKernelGGL(small_sort_kernel<true>, dim3(1), dim3(kLocalThreads), lds_bytes, stream, p, clear0, clear1);
+    } else {
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(small_sort_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (attr != hipSuccess) return attr;
+        hipLaunchKernelGGL(small_sort_kernel<false>, dim3(1), dim3(kLocalThreads), lds_bytes, stream, p, clear0, clear1);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_local_sort(const LocalSortParams& p, hipStream_t stream)
 {
     if (p.num_buckets == 0) return hipSuccess;
     if (!p.keys || !p.bases || p.width[0] == 0) return hipErrorInvalidValue;
     for (int i = 0; i < 3; i++)
         if (p.width[i] > 9 || (p.width[i] && p.shift[i] + p.width[i] > 32)) return hipErrorInvalidValue;
+    if (p.width[3]) return hipErrorInvalidValue;   // a fourth pass is launch_small_sort's
     if ((p.list == nullptr) != (p.list_count == nullptr)) return hipErrorInvalidValue;
     if (p.small_variant && p.list) return hipErrorInvalidValue;   // the list is the large variant's
     if (p.num_payloads > 3 || (p.num_payloads > 0 && !p.vals)) return hipErrorInvalidValue;

@@ -211,7 +211,7 @@ struct LocalSortParams {
     uint32_t num_payloads;       // 0 = as `vals` says (none or one)
     const uint32_t* bases;
     uint32_t num_buckets;
-    uint32_t shift[3], width[3];
+    uint32_t shift[4], width[4];   // the fourth: launch_small_sort only
     const uint32_t* skip;
     uint32_t* fault;
     uint32_t small_variant;   // 1: buckets of up to kLocalSortCapSmall keys, three workgroups per CU; 2: up to kLocalSortCapTiny, four
@@ -221,6 +221,10 @@ struct LocalSortParams {
     const uint32_t* list_count;  // grid of 512 workgroups
 };
 hipError_t launch_local_sort(const LocalSortParams& p, hipStream_t stream);
+// A whole sort of up to kLocalSortCap items in ONE launch: one workgroup loads keys (and vals, may be null), sorts all 32 bits
+// in four 8-bit digit passes inside its LDS and stores them back.  clear0 / clear1 (may be null): words the kernel zeroes first
+// (the workspace's fault word and form word: no memset launch precedes it).
+hipError_t launch_small_sort(uint32_t* keys, uint32_t* vals, uint32_t n, uint32_t* clear0, uint32_t* clear1, hipStream_t stream);
 
 // ---- the hybrid form's upfront read and planner (hybrid.hip) ------------------------------------------------------------
 // A bucket = the keys that agree on their top `bucket_bits` bits: 14 while what uniform keys put into one of 2^14 buckets (mean

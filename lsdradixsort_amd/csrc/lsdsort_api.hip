@@ -63,6 +63,10 @@ int hybrid_small_cap(size_t n, bool pairs)
     if (tiny && mean + 6.0 * std::sqrt(mean) <= (double)lsd::kLocalSortCapTiny) return lsd::kLocalSortCapTiny;
     return pairs ? lsd::kLocalSortCapSmallPairs : lsd::kLocalSortCapSmall;
 }
+std::atomic<int> g_small_sort{[] {                                      // lsdsort_set_small_sort; LSDSORT_SMALL_SORT=0 starts it off
+    const char* e = getenv("LSDSORT_SMALL_SORT");
+    return (e && e[0] == '0') ? 0 : 1;
+}()};
 std::atomic<int> g_skip_dead_passes{[] {                                // lsdsort_set_pass_skipping; LSDSORT_PASS_SKIPPING=0 starts it off
     const char* e = getenv("LSDSORT_PASS_SKIPPING");
     return (e && e[0] == '0') ? 0 : 1;
@@ -406,6 +410,14 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
         timing->passes = passes;
         timing->tile_keys = shape->tile();
         timing->tiles = (int)L.tiles;
+    }
+
+    // Up to 16384 items: one workgroup sorts them in its LDS, one launch (local_sort.hip) -- at this size the chained form's eight
+    // launches are nothing but their own latencies.  Plain uint32 keys and pairs with the returning-add rank form; not when timed.
+    if (g_small_sort.load(std::memory_order_relaxed) && n <= (size_t)lsd::kLocalSortCap && algorithm == LSDSORT_ALGO_ONESWEEP && !ev && !timing && !xf.on && more == 0 && !feed &&
+        rank_method == lsd::kRankLdsAdd && mute_row == 0) {
+        LSD_HIP(lsd::launch_small_sort(d_keys, d_vals, (uint32_t)n, control, control + kHybridOffsetWords + lsd::kHybridWordOk, stream));
+        return LSDSORT_OK;
     }
 
     if (ev) LSD_TRY(ev->mark());
@@ -850,6 +862,12 @@ int lsdsort_workspace_form(const void* d_workspace, void* hip_stream, int* hybri
                            hipMemcpyDeviceToHost, static_cast<hipStream_t>(hip_stream)));
     LSD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));
     *hybrid = ok ? 1 : 0;
+    return LSDSORT_OK;
+}
+
+int lsdsort_set_small_sort(int on)
+{
+    g_small_sort.store(on ? 1 : 0, std::memory_order_relaxed);
     return LSDSORT_OK;
 }
 

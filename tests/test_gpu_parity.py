@@ -27,10 +27,14 @@ def _sort_dev(lsd, keys, r, algo=0, vals=None):
 def rank_form(request, gpu):
     """Every rank form the library can run (lsdsort_set_rank_method): the default picks the returning LDS add where
     the device probe passed; 0 forces the architecture-guaranteed peer-mask forms (LDS OR at 8 bits, ballots at
-    4) that the library falls back to if the probe ever fails -- they must stay parity-green on their own."""
+    4) that the library falls back to if the probe ever fails -- they must stay parity-green on their own.
+    Under the forced returning add ("rank_lds_add") the one-launch sort of up to 16384 items is switched OFF, so that the chained
+    kernels keep their coverage of tiny inputs in that rank form too; "rank_auto" runs the library as shipped (one launch there)."""
     gpu.set_rank_method(request.param)
+    gpu.set_small_sort(request.param != 2)
     yield request.param
     gpu.set_rank_method(-1)
+    gpu.set_small_sort(True)
 
 
 # ----------------------------------------------------------------------------- golden vectors
@@ -875,3 +879,53 @@ def test_full_size_pairs_properties(gpu):
     same = k[1:] == k[:-1]
     assert bool((v[1:][same] > v[:-1][same]).all()), "equal keys out of input order: not stable"
     assert int(v.sum().item()) == n * (n - 1) // 2
+
+
+@pytest.mark.parametrize("pairs", [False, True])
+def test_small_sorts_are_one_launch_and_equal_the_chained_form(gpu, oracle_mod, pairs):
+    """Up to 16384 items (lsdsort_set_small_sort, on by default): one workgroup, four 8-bit digit passes in LDS.  Every size around
+    the workgroup's rows and the capacity, keys with dead digits, duplicates and the padding value; against std::sort /
+    std::stable_sort (the oracle) and against the chained form's output; 16385 items take the chained form again."""
+    import torch
+
+    rng = np.random.default_rng(77)
+    for n in (1, 2, 63, 64, 65, 511, 512, 513, 1000, 4096, 8191, 12345, 16383, 16384, 16385):
+        for kind in ("uniform", "few_values", "all_ones", "low_byte_only"):
+            keys = oracle_mod.mt19937_keys(n, n + len(kind))
+            if kind == "few_values":
+                keys = (keys % np.uint32(5)) * np.uint32(0x01010101)
+            elif kind == "all_ones":
+                keys = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+            elif kind == "low_byte_only":
+                keys = keys & np.uint32(0xFF)
+            vals = rng.permutation(n).astype(np.uint32) if pairs else None
+            got = {}
+            for on in (True, False):
+                gpu.set_small_sort(on)
+                try:
+                    got[on] = _sort_dev(gpu, keys, 8, 0, vals)
+                finally:
+                    gpu.set_small_sort(True)
+            if pairs:
+                ek, ev = oracle_mod.std_stable_sort_pairs(keys, vals)
+                for on in (True, False):
+                    assert np.array_equal(got[on][0], ek) and np.array_equal(got[on][1], ev), (n, kind, on)
+            else:
+                expect = oracle_mod.std_sort(keys)
+                for on in (True, False):
+                    assert np.array_equal(got[on], expect), (n, kind, on)
+    # a captured small sort replays like any other
+    n = 10000
+    static_k = gpu.to_device(oracle_mod.mt19937_keys(n, 5))
+    ws = gpu.alloc_workspace(n, 8)
+    gpu.GPULSDRadixSort(static_k, 8, workspace=ws)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        gpu.GPULSDRadixSort(static_k, 8, workspace=ws)
+    keys = oracle_mod.mt19937_keys(n, 6)
+    static_k.copy_(gpu.to_device(keys))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(gpu.to_host(static_k), np.sort(keys))
+    assert gpu.lib().lsdsort_check_device(ws.data_ptr(), None) == 0
