@@ -403,10 +403,11 @@ LSDSORT_API int lsdsort_set_small_sort(int on);
 LSDSORT_API int lsdsort_workspace_form(const void* d_workspace, void* hip_stream, int* hybrid);
 /* lsdsort_u32_device for a SHARD of a range-partitioned array: every key is expected to agree with the others on its top
  * `common_prefix_bits` bits (0 .. 8) -- what a rank holds after the MSB-bucket exchange of the multi-GPU sort (north_star;
- * csrc/sharded.hip calls this).  A hint, not a promise: the result is the sorted array whatever the keys are.  What it changes
- * is the hybrid form's plan: its buckets are taken below the prefix (with the prefix inside them a shard's 2^15 buckets would be
- * 2^(15 - prefix) non-empty ones, each 2^prefix times too large for the local stage, and the form would be refused); the upfront
- * read checks every key against the first and the ordinary passes run if one differs. */
+ * csrc/sharded.hip calls this).  The hybrid form takes its buckets BELOW a key prefix (with the prefix inside them a shard's 2^15
+ * buckets would be 2^(15 - prefix) non-empty ones, each 2^prefix times too large for the local stage, and the form would be
+ * refused).  Since the device finds the prefix itself -- from its 65536-key sample, for every sort (keys below 2^31, non-negative
+ * int32 keys, shards ...), checked against every key by the upfront read, 0 .. 7 bits -- the argument is only validated; the entry
+ * is kept for callers that say what they know.  The result is the sorted array whatever the keys are. */
 LSDSORT_API int lsdsort_u32_device_prefixed(uint32_t* d_keys, void* d_workspace, size_t workspace_bytes, size_t n, int radix_bits,
                                             int common_prefix_bits, void* hip_stream);
 /* Runtime tuning knob for experiments: selects among the compiled tile shapes (see

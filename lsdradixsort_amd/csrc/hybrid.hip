@@ -37,9 +37,10 @@ constexpr int kHybridVpt = 4;              // 16-byte vectors per thread per gro
 // 65536 returning atomics on one word took 0.6 ms).  A bucket's share of a workgroup's 1024 samples is 1/32 .. 1/16 of a key: eight in one
 // bucket -- 0.8 % of all keys, two hundred times a bucket's share -- raise the flag.
 __global__ void __launch_bounds__(1024) hybrid_sample_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t bucket_shift,
-                                                             uint32_t* __restrict__ hopeless, uint32_t prefix)
+                                                             uint32_t* __restrict__ words)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];   // [2^15 at most: with 2^16 buckets two neighbours share a counter]
+    __shared__ uint32_t s_differ;
     constexpr uint32_t kSamples = 65536;
     const unsigned long long step = n / kSamples;   // n >= 2^26: at least 1024
     const uint32_t tid = threadIdx.x;
@@ -49,25 +50,38 @@ __global__ void __launch_bounds__(1024) hybrid_sample_kernel(const uint32_t* __r
     const uint32_t fold = bucket_shift < 17u ? 17u - bucket_shift : 0u;
     const uint32_t counters = 1u << (32u - bucket_shift - fold);
     for (uint32_t j = tid; j < counters; j += 1024) s_cnt[j] = 0;
+    if (tid == 0) s_differ = 0;
     __syncthreads();
+    // the key prefix: bits in which no sampled key differs from the first key of the array.  All 64 workgroups OR into the plan
+    // word (the upfront read takes its leading zeros, and checks them against every key); for ITS look at the buckets a workgroup
+    // uses what its own 1024 samples say -- they span the whole array, and this look is a heuristic.
+    uint32_t d = k ^ keys[0];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) d |= __shfl_xor(d, off, kWave);
+    if ((tid & 63u) == 0u) atomicOr(&s_differ, d);
+    __syncthreads();
+    const uint32_t differ = s_differ;
+    if (tid == 0) atomicOr(&words[kHybridWordDiffer], differ);
+    uint32_t prefix = hybrid_prefix_of(differ);
+    if (prefix > kHybridMaxPrefix) prefix = 0;   // constant keys, a dead top byte: the upfront read will not run anyway
     const uint32_t mask = (1u << (32u - bucket_shift)) - 1u;
-    if (atomicAdd(&s_cnt[((k >> (bucket_shift - prefix)) & mask) >> fold], 1u) + 1u >= 8u) *hopeless = 1u;
+    if (atomicAdd(&s_cnt[((k >> (bucket_shift - prefix)) & mask) >> fold], 1u) + 1u >= 8u) words[kHybridWordHopeless] = 1u;
 }
 
-hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bits, uint32_t* hopeless, hipStream_t stream, int prefix)
+hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bits, uint32_t* words, hipStream_t stream)
 {
-    if (n < 65536u * 64u || bucket_bits < 11 || (1 << bucket_bits) > kHybridBuckets || prefix < 0 || prefix > 8) return hipErrorInvalidValue;
+    if (n < 65536u * 64u || bucket_bits < 11 || (1 << bucket_bits) > kHybridBuckets || !words) return hipErrorInvalidValue;
     const uint32_t bucket_shift = 32u - (uint32_t)bucket_bits;
     constexpr size_t lds_bytes = (size_t)32768 * sizeof(uint32_t);
     static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_sample_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(hybrid_sample_kernel, dim3(64), dim3(1024), lds_bytes, stream, keys, n, bucket_shift, hopeless, (uint32_t)prefix);
+    hipLaunchKernelGGL(hybrid_sample_kernel, dim3(64), dim3(1024), lds_bytes, stream, keys, n, bucket_shift, words);
     return hipGetLastError();
 }
 
-// R: digit width of the global passes, 8 or 4.  XF: the general instance -- typed keys, counted as to_sortable(key, xf) (the
-// identity when xf is off), and / or a key prefix: buckets and digits taken `prefix` bits lower, every key checked against the first
+// R: digit width of the global passes, 8 or 4.  XF: typed keys, counted as to_sortable(key, xf).  The key prefix (0 .. 7 bits, from
+// the sample's plan word): buckets and digits are taken that many bits lower, and every key is checked against the first.
 // B16: 2^16 buckets, counted in 16-bit halves of the same 32768 LDS words.  A half that overflows (65536 keys of one bucket in one
 // workgroup's share: nothing the local stage could take anyway) wraps or carries into its neighbour; either way the counts then
 // sum to LESS than n (every such event loses 65535 or 65536), which the planner's sum check refuses.
@@ -75,10 +89,14 @@ template <int R, bool XF, bool B16>
 __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                                uint32_t region0_keys, uint32_t* __restrict__ field_a,
                                                                                uint32_t* __restrict__ bucket, uint32_t vec_chunks,
-                                                                               const uint32_t* __restrict__ skip, uint32_t bucket_shift,
-                                                                               const KeyTransform xf, uint32_t prefix, uint32_t* __restrict__ violated)
+                                                                               uint32_t* __restrict__ words, uint32_t bucket_shift,
+                                                                               const KeyTransform xf)
 {
-    if (skip && *skip != 0u) return;   // uniform: the sample has ruled the hybrid form out (the planner then sees no counts: not ok)
+    // uniform: the sample has ruled the hybrid form out, or found a constant top byte (the ordinary form then skips a pass and
+    // moves no more bytes than this one would): nothing is counted, and the planner, seeing no counts, says no
+    if (words[kHybridWordHopeless] != 0u) return;
+    const uint32_t prefix = hybrid_prefix_of(words[kHybridWordDiffer]);
+    if (prefix > kHybridMaxPrefix) return;
     // 8-bit digits: the first pass's field, [8 position regions][256 digits], two lane-class copies.  4-bit digits: the JOINT field
     // of the first two passes, [16 position regions][bits 16-23] in one copy -- the same 4096 words and the same two LDS adds per
     // key; the planner sums it to pass A's [digit][region] and pass B's [digit][A's digit].
@@ -92,11 +110,11 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
     for (uint32_t j = tid; j < FA * CA + (B16 ? NB / 2u : NB); j += T) s_mem[j] = 0;
     __syncthreads();
 
-    const uint32_t a_shift = XF ? 16u - prefix : 16u, b_shift = XF ? bucket_shift - prefix : bucket_shift, b_mask = NB - 1u;
+    const uint32_t a_shift = 16u - prefix, b_shift = bucket_shift - prefix, b_mask = NB - 1u;
     auto slot_a = [&](uint32_t k, uint32_t region0) -> uint32_t { return ((region0 << 8) | ((k >> a_shift) & 0xFFu)) * CA; };
-    auto slot_b = [&](uint32_t k) -> uint32_t { return XF ? (k >> b_shift) & b_mask : k >> bucket_shift; };
-    const uint32_t kref = XF && n ? to_sortable(keys[0], xf) : 0u;
-    uint32_t differs = 0;   // XF: OR of (key ^ first key) over this thread's keys -- the prefix check
+    auto slot_b = [&](uint32_t k) -> uint32_t { return (k >> b_shift) & b_mask; };
+    const uint32_t kref = n ? (XF ? to_sortable(keys[0], xf) : keys[0]) : 0u;
+    uint32_t differs = 0;   // OR of (key ^ first key) over this thread's keys -- the prefix check
     auto add_b = [&](uint32_t b, uint32_t count) {   // bucket b += count
         if (B16) atomicAdd(&s_b[b >> 1], count << ((b & 1u) << 4));
         else atomicAdd(&s_b[b], count);
@@ -140,7 +158,7 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
         for (int u = 0; u < VPT; u++) {
             const uint32_t region0 = ((c + (uint32_t)u) * (uint32_t)(T * 4)) / region0_keys;   // a chunk lies in one region
             const uint32_t k4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-            if (XF) differs |= (k4[0] ^ kref) | (k4[1] ^ kref) | (k4[2] ^ kref) | (k4[3] ^ kref);
+            differs |= (k4[0] ^ kref) | (k4[1] ^ kref) | (k4[2] ^ kref) | (k4[3] ^ kref);
             if (have1) {
                 uint32_t n1 = 0, n2 = 0;
 #pragma unroll
@@ -234,10 +252,10 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
     for (size_t i = (size_t)full_chunks * (T * 4) + (size_t)blockIdx.x * T + tid; i < n; i += (size_t)gridDim.x * T)
     {
         const uint32_t k = XF ? to_sortable(keys[i], xf) : keys[i];
-        if (XF) differs |= k ^ kref;
+        differs |= k ^ kref;
         count_plain(k, (uint32_t)(i / region0_keys));
     }
-    if (XF && prefix && violated && (differs >> (32u - prefix)) != 0u) *violated = 1u;   // benign race: everybody writes 1
+    if (prefix && (differs >> (32u - prefix)) != 0u) words[kHybridWordViolated] = 1u;   // benign race: everybody writes 1
     __syncthreads();
     for (uint32_t j = tid; j < FA; j += T) {
         uint32_t cnt = 0;
@@ -257,9 +275,9 @@ __global__ void __launch_bounds__(kHybridHistThreads) hybrid_histograms_kernel(c
 }
 
 hipError_t launch_hybrid_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field_a, uint32_t* bucket,
-                                    int bucket_bits, const uint32_t* skip, hipStream_t stream, const KeyTransform& xf, int prefix, uint32_t* violated)
+                                    int bucket_bits, uint32_t* words, hipStream_t stream, const KeyTransform& xf)
 {
-    if (prefix < 0 || prefix > 8 || (prefix > 0 && !violated)) return hipErrorInvalidValue;
+    if (!words) return hipErrorInvalidValue;
     if (bucket_bits < 11 || (1 << bucket_bits) > kHybridBuckets || (radix_bits != 8 && radix_bits != 4)) return hipErrorInvalidValue;
     constexpr int T = kHybridHistThreads;
     constexpr size_t lds_bytes = (size_t)(4096 + 32768) * sizeof(uint32_t);   // 2^15 bucket counters of 32 bits or 2^16 of 16
@@ -284,8 +302,8 @@ hipError_t launch_hybrid_histograms(int radix_bits, const uint32_t* keys, uint32
     uint32_t blocks = aligned ? (vec_chunks + kHybridVpt - 1) / kHybridVpt : (n + T * 16 - 1) / (T * 16);
     if (blocks > 256) blocks = 256;
     if (blocks == 0) blocks = 1;
-#define LSD_HYB_HIST(R, XF, B16) hipLaunchKernelGGL((hybrid_histograms_kernel<R, XF, B16>), dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks, skip, 32u - (uint32_t)bucket_bits, xf, (uint32_t)prefix, violated)
-    const bool general = xf.on || prefix > 0, b16 = bucket_bits == 16;
+#define LSD_HYB_HIST(R, XF, B16) hipLaunchKernelGGL((hybrid_histograms_kernel<R, XF, B16>), dim3(blocks), dim3(T), lds_bytes, stream, keys, n, region0_keys, field_a, bucket, vec_chunks, words, 32u - (uint32_t)bucket_bits, xf)
+    const bool general = xf.on != 0, b16 = bucket_bits == 16;
     if (radix_bits == 8) {
         if (b16) { if (general) LSD_HYB_HIST(8, true, true); else LSD_HYB_HIST(8, false, true); }
         else     { if (general) LSD_HYB_HIST(8, true, false); else LSD_HYB_HIST(8, false, false); }
@@ -386,6 +404,13 @@ __global__ void __launch_bounds__(1024) hybrid_plan_kernel(const uint32_t* __res
     if (tid == 0) {
         bases[1024 * PER] = n;
         const uint32_t ok = (largest <= (uint32_t)kLocalSortCap && total == n && words[kHybridWordViolated] == 0u) ? 1u : 0u;
+        // what follows from the key prefix (the upfront read counted below it; if it did not run, nothing here is used)
+        uint32_t prefix = hybrid_prefix_of(words[kHybridWordDiffer]);
+        if (prefix > kHybridMaxPrefix) prefix = 0;
+        words[kHybridWordPrefix] = prefix;
+#pragma unroll
+        for (int g = 0; g < 4; g++) words[kHybridWordShift + g] = 16u - prefix + (uint32_t)(g * R);
+        words[kHybridWordLowBits] = 32u - prefix - (PER == 64 ? 16u : PER == 32 ? 15u : 14u);
         words[kHybridWordOk] = ok;            // the ordinary form's kernels return at once when this is set
         words[kHybridWordSkipLocal] = ok ^ 1u;
         words[kHybridWordLargeCount] = s_large;

@@ -171,17 +171,25 @@ __device__ __forceinline__ void sort_bucket(const LocalSortParams& p, const uint
         }
     };
 
-    digit_pass(p.shift[0], p.width[0]);
-    take_out(p.width[1] == 0u);
-    if (p.width[1]) {
-        digit_pass(p.shift[1], p.width[1]);
-        take_out(p.width[2] == 0u);
+    // the digits: as given, or (the hybrid form, planned on the device) bits [0, low) in one or two passes: nine bits, then the rest
+    uint32_t sh0 = p.shift[0], wd0 = p.width[0], sh1 = p.shift[1], wd1 = p.width[1], wd2 = p.width[2];
+    if (p.low_bits_word) {
+        const uint32_t low = *p.low_bits_word;   // uniform
+        sh0 = 0u; wd0 = low < 9u ? low : 9u;
+        sh1 = wd0; wd1 = low - wd0;
+        wd2 = 0u;
     }
-    if (p.width[2]) {
-        digit_pass(p.shift[2], p.width[2]);
+    digit_pass(sh0, wd0);
+    take_out(wd1 == 0u);
+    if (wd1) {
+        digit_pass(sh1, wd1);
+        take_out(wd2 == 0u);
+    }
+    if (wd2) {
+        digit_pass(p.shift[2], wd2);
         take_out(!WHOLE || p.width[3] == 0u);
     }
-    if (WHOLE && p.width[2] && p.width[3]) {
+    if (WHOLE && wd2 && p.width[3]) {
         digit_pass(p.shift[3], p.width[3]);
         take_out(true);
     }
@@ -272,18 +280,24 @@ __device__ __forceinline__ void sort_bucket_multi(const LocalSortParams& p, cons
         }
         __syncthreads();
     };
-    digit_pass(p.shift[0], p.width[0]);
-    if (p.width[1]) {
+    uint32_t sh0 = p.shift[0], wd0 = p.width[0], sh1 = p.shift[1], wd1 = p.width[1];
+    if (p.low_bits_word) {   // the hybrid form: bits [0, low), nine first (see sort_bucket)
+        const uint32_t low = *p.low_bits_word;
+        sh0 = 0u; wd0 = low < 9u ? low : 9u;
+        sh1 = wd0; wd1 = low - wd0;
+    }
+    digit_pass(sh0, wd0);
+    if (wd1) {
 #pragma unroll
         for (int i = 0; i < K; i++)
             if ((uint32_t)i < rows) {
                 first_slot[i] = slot[i];
                 key[i] = s_keys[wbase + (uint32_t)i * 64u];
             }
-        digit_pass(p.shift[1], p.width[1]);
+        digit_pass(sh1, wd1);
     }
     for (uint32_t q = tid; q < size; q += (uint32_t)T) bucket[q] = s_keys[q];   // the keys are done
-    if (p.width[1]) {
+    if (wd1) {
         __syncthreads();   // the keys have left the LDS: it now holds the second pass's slots by position ...
 #pragma unroll
         for (int i = 0; i < K; i++)
@@ -446,7 +460,7 @@ hipError_t launch_small_sort(uint32_t* keys, uint32_t* vals, uint32_t n, uint32_
 hipError_t launch_local_sort(const LocalSortParams& p, hipStream_t stream)
 {
     if (p.num_buckets == 0) return hipSuccess;
-    if (!p.keys || !p.bases || p.width[0] == 0) return hipErrorInvalidValue;
+    if (!p.keys || !p.bases || (p.width[0] == 0 && !p.low_bits_word)) return hipErrorInvalidValue;
     for (int i = 0; i < 3; i++)
         if (p.width[i] > 9 || (p.width[i] && p.shift[i] + p.width[i] > 32)) return hipErrorInvalidValue;
     if (p.width[3]) return hipErrorInvalidValue;   // a fourth pass is launch_small_sort's

@@ -106,6 +106,7 @@ struct PassParams {
     uint32_t plan_first;
     uint32_t n;
     uint32_t shift;            // bit_group * radix_bits
+    const uint32_t* shift_word;  // not null: the shift is read from here instead (the hybrid form's passes: planned on the device)
     uint32_t num_tiles;        // grid size: chained = upper bound on the regions' tile counts
     // chained (onesweep) form
     const uint32_t* regions;     // this pass's region table (device, written by the scan kernel)
@@ -212,6 +213,8 @@ struct LocalSortParams {
     const uint32_t* bases;
     uint32_t num_buckets;
     uint32_t shift[4], width[4];   // the fourth: launch_small_sort only
+    const uint32_t* low_bits_word; // not null: the stage sorts bits [0, *low_bits_word) in one or two passes (9 bits, then the
+                                   // rest) and shift / width are ignored (the hybrid form: planned on the device)
     const uint32_t* skip;
     uint32_t* fault;
     uint32_t small_variant;   // 1: buckets of up to kLocalSortCapSmall keys, three workgroups per CU; 2: up to kLocalSortCapTiny, four
@@ -249,8 +252,16 @@ constexpr int kHybridWordPlan = 2;        // PassParams::plan of the g-th global
 constexpr int kHybridWordLargest = 10;    // the largest bucket (diagnostics)
 constexpr int kHybridWordLargeCount = 11; // buckets above the small variant's capacity: the entries of the planner's list
 constexpr int kHybridWordHopeless = 12;   // 1: a sample of the keys already shows a bucket far above the capacity: the upfront read is skipped
-constexpr int kHybridWordViolated = 13;   // 1: the caller's common key prefix does not hold (some key differs in its top bits): ordinary form
-constexpr int kHybridWords = 14;
+constexpr int kHybridWordViolated = 13;   // 1: the sampled key prefix does not hold (some key differs in its top bits): ordinary form
+constexpr int kHybridWordDiffer = 14;     // OR of (key ^ first key) over the 65536 sampled keys: its leading zeros are the prefix
+constexpr int kHybridWordPrefix = 15;     // t = the prefix the form was planned for (0 .. kHybridMaxPrefix), written by the planner
+constexpr int kHybridWordShift = 16;      // [4]: PassParams::shift of the g-th global pass = 16 - t + g x radix_bits
+constexpr int kHybridWordLowBits = 20;    // the local stage's bits: 32 - t - bucket_bits
+constexpr int kHybridWords = 21;
+// A prefix of eight bits or more is a constant top byte: the ordinary form then skips a pass and moves as few bytes as the hybrid
+// form would, so the form is only planned for 0 .. 7 shared bits.
+constexpr uint32_t kHybridMaxPrefix = 7;
+__host__ __device__ inline uint32_t hybrid_prefix_of(uint32_t differ) { return differ ? (uint32_t)__builtin_clz(differ) : 32u; }
 // The global passes of the hybrid form cover bits 16-31: two at 8-bit digits, four at 4-bit digits.
 inline constexpr int hybrid_global_passes(int radix_bits) { return 16 / radix_bits; }
 // Count words of the form (zeroed with the workspace): the passes' [pass][digit][region] fields (8-bit: A from the upfront read,
@@ -259,23 +270,24 @@ inline constexpr int hybrid_global_passes(int radix_bits) { return 16 / radix_bi
 inline constexpr size_t hybrid_field_words(int radix_bits) { return radix_bits == 8 ? 2 * 2048 : 4 * 256; }
 inline constexpr size_t hybrid_joint_words(int radix_bits) { return radix_bits == 8 ? 0 : 16 * 256; }
 inline constexpr size_t hybrid_count_words(int radix_bits) { return hybrid_field_words(radix_bits) + hybrid_joint_words(radix_bits) + kHybridBuckets; }
-// A look at 65536 keys taken at a regular stride: *hopeless = 1 if some bucket holds 0.8 % or more of a workgroup's 1024 samples
-// (its share is 0.003 %): such keys cannot take the hybrid form, and the 0.2-0.3 ms of its upfront read are saved (zeros, a default
-// value, small ranges, few-valued keys).
-// `prefix` (here and below): the number of top bits every key is expected to share (a shard of an array partitioned by its top
-// bits).  Buckets are then the bucket_bits bits BELOW the prefix, the global passes' digits start at bit 16 - prefix.
-hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bits, uint32_t* hopeless, hipStream_t stream, int prefix = 0);
+// The key prefix: the top bits every key shares (keys below 2^31, a shard of an array partitioned by its top bits, ...).  Buckets
+// are the bucket_bits bits BELOW it and the global passes' digits start at bit 16 - prefix; with the prefix inside them the buckets
+// would be 2^(bucket_bits - prefix) non-empty ones, each 2^prefix times too large.  The sample finds it (words[kHybridWordDiffer]),
+// the upfront read checks it against every key (words[kHybridWordViolated]), the planner writes what follows from it.
+// A look at 65536 keys taken at a regular stride: words[Differ] |= key ^ first key, and words[Hopeless] = 1 if some bucket holds
+// 0.8 % or more of a workgroup's 1024 samples (its share is 0.003 %): such keys cannot take the hybrid form, and the 0.2-0.3 ms of
+// its upfront read are saved (zeros, a default value, small ranges, few-valued keys).
+hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bits, uint32_t* words, hipStream_t stream);
 // 8-bit digits: field[(digit of bits 16-23) * 8 + position region]; 4-bit digits: field[position region * 256 + bits 16-23] (the
-// joint field); and bucket[key >> (32 - bucket_bits)] += counts (all zero on entry).  *skip != 0: nothing
-// xf: the keys are counted as to_sortable(key, xf) (typed sorts: what the first global pass will store)
+// joint field); and bucket[key >> (32 - bucket_bits)] += counts (all zero on entry) -- bits counted below the prefix.
+// Nothing if words[Hopeless] or the sampled prefix is eight bits or more.  xf: the keys are counted as to_sortable(key, xf)
+// (typed sorts: what the first global pass will store).
 hipError_t launch_hybrid_histograms(int radix_bits, const uint32_t* keys, uint32_t n, uint32_t region0_keys, uint32_t* field, uint32_t* bucket,
-                                    int bucket_bits, const uint32_t* skip, hipStream_t stream, const KeyTransform& xf = KeyTransform{},
-                                    int prefix = 0, uint32_t* violated = nullptr);   // *violated |= 1 if a key differs from the first in its top `prefix` bits
+                                    int bucket_bits, uint32_t* words, hipStream_t stream, const KeyTransform& xf = KeyTransform{});
 // verdict, bucket bases (2^bucket_bits + 1 words), plan words and the count fields the upfront read has not written: 8-bit digits
 // fields_out = the second pass's field B [256][8] (joint unused); 4-bit digits fields_out = all four passes' [4][16][16], from
 // joint and the buckets
 // ... and large_list[0 .. words[kHybridWordLargeCount]): the buckets of more than small_cap keys (up to 2^bucket_bits words)
-// words[kHybridWordViolated] != 0 on entry (the upfront read's check of the key prefix): not ok
 hipError_t launch_hybrid_plan(int radix_bits, const uint32_t* bucket, uint32_t n, int bucket_bits, uint32_t* bases, uint32_t* fields_out,
                               const uint32_t* joint, uint32_t* words, uint32_t* large_list, uint32_t small_cap, hipStream_t stream);
 

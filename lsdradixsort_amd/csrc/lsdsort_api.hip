@@ -37,7 +37,7 @@ thread_local hipError_t g_last_hip = hipSuccess;
     } while (0)
 
 constexpr size_t kAlign = 256;
-constexpr size_t kControlBytes = 256;            // u32[64]: [0] fault word, [16 .. 16 + kPlanWords) the pass plan
+constexpr size_t kControlBytes = 512;            // u32[128]: [0] fault word, [16 .. 16 + kPlanWords) the pass plan, then the hybrid form's words
 constexpr size_t kPlanOffsetWords = 16;
 constexpr size_t kHybridOffsetWords = kPlanOffsetWords + lsd::kPlanWords + 1;   // the hybrid form's plan words (hybrid.hip)
 static_assert(kHybridOffsetWords + lsd::kHybridWords <= kControlBytes / sizeof(uint32_t), "the plans live in the control block");
@@ -371,7 +371,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
              int algorithm, hipStream_t stream, StageEvents* ev, lsdsort_timing* timing,
              const lsd::KeyTransform& xf = lsd::KeyTransform{}, const HostFeed* feed = nullptr,
              uint32_t* const* d_more = nullptr, int more = 0,   // further payload arrays (0..2), chained form only
-             int prefix = 0)   // top bits the keys are expected to share (lsdsort_u32_device_prefixed): a hint for the hybrid form's plan
+             int prefix = 0)   // lsdsort_u32_device_prefixed's argument: checked, not needed (the device finds the key prefix itself)
 {
     if (prefix < 0 || prefix > 8) return LSDSORT_ERR_INVALID_ARG;
     if (more < 0 || more > 2 || (more > 0 && (!d_vals || !d_more || algorithm != LSDSORT_ALGO_ONESWEEP || feed))) return LSDSORT_ERR_INVALID_ARG;
@@ -455,9 +455,9 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             uint32_t* joint = fields + lsd::hybrid_field_words(radix_bits);
             uint32_t* bucket = joint + lsd::hybrid_joint_words(radix_bits);
             const int bb = lsd::hybrid_bucket_bits(n, pairs);
-            LSD_HIP(lsd::launch_hybrid_sample(d_keys, (uint32_t)n, bb, hyb + lsd::kHybridWordHopeless, stream, prefix));
+            LSD_HIP(lsd::launch_hybrid_sample(d_keys, (uint32_t)n, bb, hyb, stream));
             LSD_HIP(lsd::launch_hybrid_histograms(radix_bits, d_keys, (uint32_t)n, L.region0, radix_bits == 8 ? fields : joint, bucket, bb,
-                                                  hyb + lsd::kHybridWordHopeless, stream, xf, prefix, hyb + lsd::kHybridWordViolated));
+                                                  hyb, stream, xf));
             uint32_t* bases = reinterpret_cast<uint32_t*>(ws + L.hyb_bases);
             LSD_HIP(lsd::launch_hybrid_plan(radix_bits, bucket, (uint32_t)n, bb, bases, radix_bits == 8 ? fields + 2048 : fields, joint, hyb,
                                             bases + lsd::kHybridBuckets + 1,
@@ -539,7 +539,8 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
                     p.more_out[e] = reinterpret_cast<uint32_t*>(ws + L.alt_more[e]);
                 }
                 p.n = (uint32_t)n;
-                p.shift = (uint32_t)(16 - prefix + radix_bits * g);   // bits [16 - prefix, 32 - prefix): the prefix above them is constant
+                p.shift = (uint32_t)(16 + radix_bits * g);
+                p.shift_word = hyb + lsd::kHybridWordShift + g;   // ... less the key prefix the device found: bits [16 - t, 32 - t)
                 p.num_tiles = L.rows;
                 p.fault = control;
                 p.spin_limit = g_spin_limit.load(std::memory_order_relaxed);
@@ -563,9 +564,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             lp.bases = reinterpret_cast<const uint32_t*>(ws + L.hyb_bases);
             const int bb = lsd::hybrid_bucket_bits(n, pairs);
             lp.num_buckets = 1u << bb;
-            const int low_bits = 32 - prefix - bb;   // the 17 (18) bits below a bucket's own, fewer under a prefix: bits 0-8, then the rest
-            lp.shift[0] = 0; lp.width[0] = (uint32_t)(low_bits < 9 ? low_bits : 9);
-            lp.shift[1] = lp.width[0]; lp.width[1] = (uint32_t)low_bits - lp.width[0];   // 0: one digit pass
+            lp.low_bits_word = hyb + lsd::kHybridWordLowBits;   // the bits below a bucket's own: 32 - bb less the key prefix the device found
             lp.skip = hyb + lsd::kHybridWordSkipLocal;
             lp.xout = xf;
             lp.fault = control;

@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
-    const uint32_t shift = p.shift;
+    const uint32_t shift = p.shift_word ? *p.shift_word : p.shift;   // uniform (the hybrid form's passes: planned on the device)
     // Digit of a key.  The narrow-digit kernels double as the splitter partition (PassParams): there the
     // digit is the key's bucket.  Wider digits compile to the plain bit-field extract.
     auto digit_of = [&](uint32_t k) -> uint32_t {

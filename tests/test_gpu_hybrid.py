@@ -217,12 +217,14 @@ def test_typed_keys_take_the_hybrid_form(gpu, key_type, descending, radix, log2n
             gpu.set_hybrid(True)
 
 
-@pytest.mark.parametrize("prefix,radix,log2n", [(1, 8, 27), (3, 8, 27), (3, 8, 26), (4, 8, 28), (3, 4, 27), (8, 8, 26)])
-def test_prefixed_shard_takes_the_hybrid_form(gpu, prefix, radix, log2n):
-    """lsdsort_u32_device_prefixed: a shard of a range-partitioned array (every key carries the same top `prefix` bits, as after
-    the MSB-bucket exchange of the multi-GPU sort).  With the hint the hybrid form plans its buckets below the prefix and runs;
-    without it the same keys fill 2^(15 - prefix) buckets 2^prefix times too large and the ordinary passes run.  Same result, equal
-    to torch.sort.  A hint that does not hold (uniform keys, prefix claimed) is caught by the upfront read: ordinary passes."""
+@pytest.mark.parametrize("prefix,radix,log2n", [(1, 8, 27), (1, 8, 28), (3, 8, 27), (3, 8, 26), (4, 8, 28), (7, 8, 27), (3, 4, 27), (8, 8, 26)])
+def test_keys_that_share_a_prefix_take_the_hybrid_form(gpu, prefix, radix, log2n):
+    """Keys that share their top bits -- values below 2^31, a shard of a range-partitioned array (what a rank holds after the
+    MSB-bucket exchange of the multi-GPU sort).  With the prefix inside them such keys fill 2^(15 - prefix) buckets 2^prefix times
+    too large; the device finds the prefix (65536-key sample), plans its buckets below it, checks it against every key in the
+    upfront read -- up to seven bits; a constant top byte is the ordinary form's business (it skips a pass).  Through the plain
+    entry and through lsdsort_u32_device_prefixed (whose argument is only validated); bit-exact against torch.sort.  One key
+    outside the prefix, where the sample does not look: the upfront read notices, ordinary passes, same result."""
     import torch
 
     n = (1 << log2n) + 777
@@ -235,57 +237,44 @@ def test_prefixed_shard_takes_the_hybrid_form(gpu, prefix, radix, log2n):
     ws = gpu.alloc_workspace(n, radix)
     stream = torch.cuda.current_stream().cuda_stream
     L = gpu.lib()
+    form = 1 if prefix <= 7 else 0
 
-    d = keys.clone()
-    assert L.lsdsort_u32_device_prefixed(d.data_ptr(), ws.data_ptr(), ws.numel(), n, radix, prefix, stream) == 0
-    assert gpu.workspace_form(ws) == 1, "with the hint the hybrid form runs"
-    assert L.lsdsort_check_device(ws.data_ptr(), stream) == 0
-    assert torch.equal(_u64(d), expect)
-
-    d = keys.clone()
-    assert L.lsdsort_u32_device_prefixed(d.data_ptr(), ws.data_ptr(), ws.numel(), n, radix, 0, stream) == 0
-    # without the hint: non-empty buckets are 2^prefix times the average -- 16384 keys and more
-    assert gpu.workspace_form(ws) == 0
-    assert torch.equal(_u64(d), expect)
-
-    # the hint does not hold: one key elsewhere, then uniform keys
-    for wrong in (torch.cat([keys[:-1], _i32(torch.tensor([5], device="cuda", dtype=torch.int64))]), base):
-        d = wrong.clone()
-        assert L.lsdsort_u32_device_prefixed(d.data_ptr(), ws.data_ptr(), ws.numel(), n, radix, prefix, stream) == 0
-        assert gpu.workspace_form(ws) == 0, "a key outside the prefix: the ordinary passes"
+    for hint in (prefix, 0):
+        d = keys.clone()
+        assert L.lsdsort_u32_device_prefixed(d.data_ptr(), ws.data_ptr(), ws.numel(), n, radix, hint, stream) == 0
+        assert gpu.workspace_form(ws) == form, (hint, gpu.workspace_form(ws))
         assert L.lsdsort_check_device(ws.data_ptr(), stream) == 0
-        assert torch.equal(_u64(d), torch.sort(_u64(wrong)).values)
+        assert torch.equal(_u64(d), expect)
+    d = keys.clone()
+    gpu.GPULSDRadixSort(d, radix, workspace=ws, check_fault=True)
+    assert gpu.workspace_form(ws) == form and torch.equal(_u64(d), expect)
+
+    # one key outside the prefix, at the far end (not a sample position): the exact check refuses, the result is still right
+    wrong = torch.cat([keys[:-1], _i32(torch.tensor([5], device="cuda", dtype=torch.int64))])
+    d = wrong.clone()
+    gpu.GPULSDRadixSort(d, radix, workspace=ws, check_fault=True)
+    assert gpu.workspace_form(ws) == 0, "a key outside the sampled prefix: the ordinary passes"
+    assert torch.equal(_u64(d), torch.sort(_u64(wrong)).values)
     assert L.lsdsort_u32_device_prefixed(d.data_ptr(), ws.data_ptr(), ws.numel(), n, radix, 9, stream) != 0
 
 
-def test_hybrid_in_a_hip_graph_and_from_an_unaligned_base(gpu):
-    """The form is chosen on the device from plan words in the workspace, so a captured sort chooses anew at every replay: one
-    graph, replayed on keys the hybrid form takes (uniform) and on keys it must refuse (half zeros).  The key array starts one
-    word past a 16-byte boundary: the upfront read takes its scalar path, the passes and the local stage their ragged edges."""
+def test_non_negative_int32_keys_take_the_hybrid_form(gpu):
+    """The commonest prefix there is: int32 keys that are all >= 0 (sortable form: top bit set in every key)."""
     import torch
 
-    n = (1 << 26) + 4242
+    n = (1 << 27) + 99
     gen = torch.Generator(device="cuda")
-    gen.manual_seed(11)
-    backing = torch.empty(n + 1, dtype=torch.int32, device="cuda")
-    static_k = backing[1:]
-    assert static_k.data_ptr() % 16 == 4
+    gen.manual_seed(17)
+    keys = torch.randint(0, (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda", generator=gen)
     ws = gpu.alloc_workspace(n, 8)
-    uniform = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda", generator=gen)
-    half_zero = torch.where((uniform & 0x2000) != 0, uniform, torch.zeros_like(uniform))
-    static_k.copy_(uniform)
-    gpu.GPULSDRadixSort(static_k, 8, workspace=ws)                        # warm-up outside the capture
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        gpu.GPULSDRadixSort(static_k, 8, workspace=ws)
-    for keys, form in ((uniform, 1), (half_zero, 0), (uniform, 1)):
-        static_k.copy_(keys)
-        graph.replay()
-        torch.cuda.synchronize()
-        assert gpu.workspace_form(ws) == form
-        assert torch.equal(_u64(static_k), torch.sort(_u64(keys)).values), form
-        assert gpu.lib().lsdsort_check_device(ws.data_ptr(), None) == 0
+    d = keys.clone()
+    gpu.GPUSortTyped(d, "int32", False, r=8, workspace=ws, check_fault=True)
+    assert gpu.workspace_form(ws) == 1
+    assert torch.equal(d, torch.sort(keys).values)
+    d = keys.clone()
+    gpu.GPUSortTyped(d, "int32", True, r=8, workspace=ws, check_fault=True)
+    assert gpu.workspace_form(ws) == 1
+    assert torch.equal(d, torch.sort(keys, descending=True).values)
 
 
 @pytest.mark.parametrize("payloads,radix,log2n", [(2, 8, 26), (3, 8, 27), (3, 4, 26)])
