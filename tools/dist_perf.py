@@ -28,6 +28,11 @@ cases = {
     "90pct_one_value": lambda: np.where((base % np.uint32(10)) != 0, np.uint32(0x80000001), base).astype(np.uint32),
     "two_values": lambda: np.where(base & np.uint32(1 << 17), np.uint32(0x11111111), np.uint32(0xEEEEEEEE)).astype(np.uint32),
     "four_values_per_digit": lambda: base & np.uint32(0x03030303),
+    # shapes the hybrid form meets: a shared key prefix, dead low bits (one digit of the local stage constant), few low values
+    "below_2^31": lambda: base >> np.uint32(1),
+    "below_2^29": lambda: base >> np.uint32(3),
+    "multiples_of_512": lambda: base & np.uint32(0xFFFFFE00),
+    "low_byte_of_4_values": lambda: base & np.uint32(0xFFFFFF03),
 }
 if a.only:
     cases = {k: v for k, v in cases.items() if k in a.only}
