@@ -122,6 +122,10 @@ def test_hybrid_pairs_are_stable(gpu, n):
     shapes = {
         "uniform": (lambda: base.clone(), 1),
         "duplicates_in_buckets": (lambda: _i32(_u64(base) & 0xFFFE0F0F), 1),
+        # a local digit that is the same for every key of a bucket is skipped (local_sort.hip): the payloads must stay in input
+        # order among equal keys all the same
+        "first_local_digit_dead": (lambda: _i32(_u64(base) & 0xFFFFFE00), 1),
+        "second_local_digit_dead": (lambda: _i32(_u64(base) & 0xFFFC01FF), 1),
         "half_zero": (lambda: _i32(torch.where(((_u64(base) >> 13) & 1) != 0, _u64(base), torch.zeros_like(_u64(base)))), 0),
     }
     for name, (make, expect_hybrid) in shapes.items():
