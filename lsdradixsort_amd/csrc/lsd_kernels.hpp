@@ -231,8 +231,8 @@ hipError_t launch_small_sort(uint32_t* keys, uint32_t* vals, uint32_t n, uint32_
 
 // ---- the hybrid form's upfront read and planner (hybrid.hip) ------------------------------------------------------------
 // A bucket = the keys that agree on their top `bucket_bits` bits: 14 while what uniform keys put into one of 2^14 buckets (mean
-// + 6 sigma) fits the three-per-CU variant of the local stage (10240 keys, 8192 pairs), 15 up to an average of 14648 keys a
-// bucket (4.8e8 items), 16 above (to 9.6e8 items).  Larger buckets are cheaper per key (a bucket's scans, barriers and its
+// + 6 sigma) fits the three-per-CU variant of the local stage (10240 keys, 8192 pairs), 15 while nearly all of 2^15 buckets do (mean + 1.5 sigma),
+// 16 above (to 9.6e8 items).  Larger buckets are cheaper per key (a bucket's scans, barriers and its
 // unoverlapped first load and last store are per bucket: 2^27 keys in buckets of 4096 cost the local stage 0.35-0.39 ms, in
 // buckets of 8192 0.29).  Every table is sized for 2^16.
 constexpr int kHybridBuckets = 1 << 16;
@@ -243,7 +243,14 @@ constexpr int hybrid_bucket_bits(size_t n, bool pairs)
     size_t root = 1;                               // ceil(sqrt(mean)), no <cmath> in device headers
     while (root * root < mean) root++;
     if (mean + 6 * root <= cap) return 14;
-    return (n >> 15) <= kHybridMaxMeanBucket ? 15 : 16;
+    // 2^15 buckets while nearly all of them still fit that variant (mean + 1.5 sigma: a few per cent go on the planner's list);
+    // beyond, 2^16 buckets of half the size beat the list's one- or two-per-CU variant (400e6 keys 152 -> 160 Gkeys/s, 2^28 pairs
+    // 81 -> 93 Gpairs/s; at 330e6 keys, a mean of 10071, the list of the few larger ones is still ahead: 159-162 against 153; at
+    // 360e6, a mean of 10986, no longer: 146)
+    const size_t mean15 = n >> 15;
+    size_t root15 = 1;
+    while (root15 * root15 < mean15) root15++;
+    return 2 * mean15 + 3 * root15 <= 2 * cap ? 15 : 16;
 }
 // plan words (uint32, in the workspace's control block): written by the planner, read by every kernel of either form
 constexpr int kHybridWordOk = 0;          // 1: the hybrid form runs (the ordinary form's kernels return at once)
