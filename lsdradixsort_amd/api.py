@@ -115,7 +115,7 @@ def set_xcd_chunk(chunk: int) -> None:
 
 
 def set_hybrid(on: bool) -> None:
-    """The hybrid form of sorts of 2^26 .. 9.6e8 items with 8- or 4-bit digits (global passes on bits 16-31 + an LDS-resident local
+    """The hybrid form of sorts of 2^25 .. 9.6e8 items with 8- or 4-bit digits (global passes on bits 16-31 + an LDS-resident local
     stage, decided on the device; ``lsdsort_set_hybrid``).  Default on; off = every digit through global memory, always."""
     check(lib().lsdsort_set_hybrid(1 if on else 0), "lsdsort_set_hybrid")
 

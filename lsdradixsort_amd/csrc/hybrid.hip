@@ -1,4 +1,4 @@
-// hybrid.hip -- stage 1 and the planner of the HYBRID form (2^26 .. 9.6e8 items; 8- or 4-bit digits; keys, pairs, records; typed keys).
+// hybrid.hip -- stage 1 and the planner of the HYBRID form (2^25 .. 9.6e8 items; 8- or 4-bit digits; keys, pairs, records; typed keys).
 // Written below for its first shape -- 8-bit digits, 2^15 buckets; what differs at 4-bit digits, with 2^14 buckets, for typed keys
 // and for shards that share a key prefix is said at the kernels.
 //
