@@ -666,8 +666,8 @@ static hipError_t launch_joint_inst(const uint32_t* keys, uint32_t n, uint32_t r
     static_assert(lds_bytes <= 160 * 1024, "counters and rings must fit one CU's LDS");
     auto kernel = joint_histograms_kernel<R, THREADS, WIDE, DMA>;
     if (lds_bytes > 64 * 1024) {
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        static std::atomic<uint64_t> told{0};
+        const hipError_t attr = allow_dynamic_lds(reinterpret_cast<const void*>(kernel), lds_bytes, told);
         if (attr != hipSuccess) return attr;
     }
     if (region0_keys == 0 || region0_keys % (THREADS * 4) != 0 || first_key % (THREADS * 4) != 0) return hipErrorInvalidValue;

@@ -73,8 +73,8 @@ hipError_t launch_hybrid_sample(const uint32_t* keys, uint32_t n, int bucket_bit
     if (n < 65536u * 64u || bucket_bits < 11 || (1 << bucket_bits) > kHybridBuckets || !words) return hipErrorInvalidValue;
     const uint32_t bucket_shift = 32u - (uint32_t)bucket_bits;
     constexpr size_t lds_bytes = (size_t)32768 * sizeof(uint32_t);
-    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_sample_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    static std::atomic<uint64_t> told{0};
+        const hipError_t attr = allow_dynamic_lds(reinterpret_cast<const void*>(hybrid_sample_kernel), lds_bytes, told);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(hybrid_sample_kernel, dim3(64), dim3(1024), lds_bytes, stream, keys, n, bucket_shift, words);
     return hipGetLastError();
@@ -284,17 +284,23 @@ hipError_t launch_hybrid_histograms(int radix_bits, const uint32_t* keys, uint32
     static_assert(2048 * kHybridCopiesA == 4096, "both digit widths keep 4096 field counters");
     static_assert(lds_bytes <= 160 * 1024, "one workgroup per CU");
     if (region0_keys == 0 || region0_keys % (T * 4) != 0) return hipErrorInvalidValue;
-    static hipError_t attr = [] {
+    static std::atomic<uint64_t> told{0};
+    hipError_t attr = hipSuccess;
+    {
+        int dev = 0;
+        attr = hipGetDevice(&dev);
+        if (attr == hipSuccess && !(told.load(std::memory_order_acquire) & (1ull << (dev & 63)))) {
 #define LSD_K(R, XF, B16) reinterpret_cast<const void*>(hybrid_histograms_kernel<R, XF, B16>)
-        const void* kernels[8] = {LSD_K(8, false, false), LSD_K(8, true, false), LSD_K(4, false, false), LSD_K(4, true, false),
-                                  LSD_K(8, false, true),  LSD_K(8, true, true),  LSD_K(4, false, true),  LSD_K(4, true, true)};
+            const void* kernels[8] = {LSD_K(8, false, false), LSD_K(8, true, false), LSD_K(4, false, false), LSD_K(4, true, false),
+                                      LSD_K(8, false, true),  LSD_K(8, true, true),  LSD_K(4, false, true),  LSD_K(4, true, true)};
 #undef LSD_K
-        for (const void* k : kernels) {
-            const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            if (e != hipSuccess) return e;
+            for (const void* k : kernels) {
+                attr = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                if (attr != hipSuccess) break;
+            }
+            if (attr == hipSuccess) told.fetch_or(1ull << (dev & 63), std::memory_order_release);
         }
-        return hipSuccess;
-    }();
+    }
     if (attr != hipSuccess) return attr;
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const uint32_t vec_chunks = aligned ? n / (T * 4) : 0;

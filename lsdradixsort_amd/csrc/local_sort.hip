@@ -373,7 +373,8 @@ static hipError_t launch_local_multi(const LocalSortParams& p, hipStream_t strea
     if (p.list) {
         if constexpr (K == 32) {   // the list is the large variant's (three register arrays of 32: one workgroup per CU, as the pairs')
             auto kernel = local_sort_multi_list_kernel<K>;
-            static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            static std::atomic<uint64_t> told{0};
+        const hipError_t attr = allow_dynamic_lds(reinterpret_cast<const void*>(kernel), lds_bytes, told);
             if (attr != hipSuccess) return attr;
             hipLaunchKernelGGL(kernel, dim3(256), dim3(kLocalThreads), lds_bytes, stream, p);
             return hipGetLastError();
@@ -381,7 +382,8 @@ static hipError_t launch_local_multi(const LocalSortParams& p, hipStream_t strea
         return hipErrorInvalidValue;
     }
     auto kernel = local_sort_multi_kernel<K>;
-    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    static std::atomic<uint64_t> told{0};
+        const hipError_t attr = allow_dynamic_lds(reinterpret_cast<const void*>(kernel), lds_bytes, told);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(kernel, dim3(p.num_buckets), dim3(kLocalThreads), lds_bytes, stream, p);
     return hipGetLastError();
@@ -427,7 +429,8 @@ static hipError_t launch_local_inst_x(const LocalSortParams& p, hipStream_t stre
     if (p.list) {
         if constexpr (K == 32) {   // the list is the large variant's
             auto kernel = local_sort_list_kernel<K, PAIRS, XOUT>;
-            static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            static std::atomic<uint64_t> told{0};
+        const hipError_t attr = allow_dynamic_lds(reinterpret_cast<const void*>(kernel), lds_bytes, told);
             if (attr != hipSuccess) return attr;
             hipLaunchKernelGGL(kernel, dim3(512), dim3(kLocalThreads), lds_bytes, stream, p);   // two workgroups per CU walk the list
             return hipGetLastError();
@@ -436,7 +439,8 @@ static hipError_t launch_local_inst_x(const LocalSortParams& p, hipStream_t stre
     }
     auto kernel = local_sort_kernel<K, PAIRS, XOUT>;
     if (lds_bytes > 64 * 1024) {
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        static std::atomic<uint64_t> told{0};
+        const hipError_t attr = allow_dynamic_lds(reinterpret_cast<const void*>(kernel), lds_bytes, told);
         if (attr != hipSuccess) return attr;
     }
     hipLaunchKernelGGL(kernel, dim3(p.num_buckets), dim3(kLocalThreads), lds_bytes, stream, p);
@@ -468,11 +472,13 @@ hipError_t launch_small_sort(uint32_t* keys, uint32_t* vals, uint32_t n, uint32_
     }
     constexpr size_t lds_bytes = local_lds_words<32>() * sizeof(uint32_t);
     if (vals) {
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(small_sort_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        static std::atomic<uint64_t> told{0};
+        const hipError_t attr = allow_dynamic_lds(reinterpret_cast<const void*>(small_sort_kernel<true>), lds_bytes, told);
         if (attr != hipSuccess) return attr;
         hipLaunchKernelGGL(small_sort_kernel<true>, dim3(1), dim3(kLocalThreads), lds_bytes, stream, p, clear0, clear1);
     } else {
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(small_sort_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        static std::atomic<uint64_t> told{0};
+        const hipError_t attr = allow_dynamic_lds(reinterpret_cast<const void*>(small_sort_kernel<false>), lds_bytes, told);
         if (attr != hipSuccess) return attr;
         hipLaunchKernelGGL(small_sort_kernel<false>, dim3(1), dim3(kLocalThreads), lds_bytes, stream, p, clear0, clear1);
     }

@@ -4,6 +4,8 @@
 // instantiation for (radix_bits, tile shape) and returns the hipError_t of the launch.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -70,6 +72,20 @@ __host__ __device__ inline uint32_t from_sortable(uint32_t t, const KeyTransform
 {
     const uint32_t u = t ^ x.c;
     return u ^ ((uint32_t)((int32_t)(~u & x.a) >> 31) | x.b);
+}
+
+// Kernels that ask for more than 64 KiB of dynamic LDS say so once PER DEVICE (a process may drive several: lsdsort_u32_ex with
+// num_gpus > 1 runs one host thread per device): `done` is the call site's own bit set of devices already told.
+inline hipError_t allow_dynamic_lds(const void* kernel, size_t bytes, std::atomic<uint64_t>& done)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
 }
 
 // Set (per host thread) around a rank-and-scatter launch by lsdsort_u32_device_timed: events that

@@ -909,8 +909,8 @@ hipError_t launch_rank_scatter_inst(const PassParams& p, hipStream_t stream)
     constexpr size_t lds_bytes = (size_t)rank_scatter_lds_words<R, T, K, CAP, RANK>() * sizeof(uint32_t);
     auto kernel = rank_scatter_kernel<R, T, K, CAP, RANK, PAIRS, CHAINED, XF>;
     if (lds_bytes > 64 * 1024) {
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        static std::atomic<uint64_t> told{0};
+        const hipError_t attr = allow_dynamic_lds(reinterpret_cast<const void*>(kernel), lds_bytes, told);
         if (attr != hipSuccess) return attr;
     }
 #ifdef LSD_PHASE_STATS
