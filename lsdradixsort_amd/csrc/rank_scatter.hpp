@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
     // h2 = the first value in the row that differs from it (kNoDigit if there is none).
     constexpr uint32_t kHeavy = 16;
     constexpr uint32_t kNoDigit = 0xFFFFFFFFu;
-    auto pick_heavy = [&](uint32_t d, uint32_t& h1, uint32_t& h2) -> bool {
+    auto pick_heavy = [&](uint32_t d, uint32_t d_last, uint32_t& h1, uint32_t& h2) -> bool {
         const uint32_t a = __builtin_amdgcn_readfirstlane(d), b = (uint32_t)__builtin_amdgcn_readlane((int)d, 32);
         const uint64_t ma = __ballot(d == a), mb = __ballot(d == b);
         const uint32_t na = popc64_add(ma, 0u), nb = popc64_add(mb, 0u);
@@ -199,6 +199,14 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         // a second value is worth its ballots only if it is frequent as well (eight lanes of the row); otherwise its
         // few holders take their atomics like everybody else and the careful loop counts ONE value
         if (h2 != kNoDigit && popc64_add(__ballot(d == h2), 0u) < 8u) h2 = kNoDigit;
+        // Runs (sorted input, or the hybrid form's passes on position-correlated high bits: 4096 keys of one digit in a row, a
+        // wave holds 2048): the first row knows only the run the wave STARTS in; half of the waves end in the next one, whose keys
+        // would all take the same atomic, 64 lanes on one word, row after row (round 3: 10.7 us of rank phase per tile instead
+        // of 3.2).  The wave's last key names that second value.
+        if (h2 == kNoDigit) {
+            const uint32_t z = (uint32_t)__builtin_amdgcn_readlane((int)d_last, 63);
+            if (z != h1) h2 = z;
+        }
         return true;
     };
     auto row_is_heavy = [&](uint32_t d) -> bool {
@@ -461,7 +469,7 @@ __global__ void __launch_bounds__(T, (min_waves_per_simd<T, K>())) rank_scatter_
         // end (no atomic ever touches those two words: a key either has the value or it has not).  Uniform random input
         // takes the straight path, where the K atomics issue back to back.
         uint32_t h1 = 0, h2 = 0;
-        if (pick_heavy(digit_of(key[0]), h1, h2)) {
+        if (pick_heavy(digit_of(key[0]), digit_of(key[K - 1]), h1, h2)) {
             // first every key that holds neither value takes its returning add (nothing else writes rank[] in this loop, so
             // the adds issue one after the other and nothing waits for them) ...
 #pragma unroll

@@ -13,12 +13,15 @@ ap.add_argument("--algos", type=int, nargs="*", default=[0, 1])
 ap.add_argument("--mask", type=lambda x: int(x, 0), default=0xFFFFFFFF)
 ap.add_argument("--radix", type=int, default=8)
 ap.add_argument("--heavy", type=int, default=0, help="percent of the keys set to one value (0x80000001)")
+ap.add_argument("--sorted", action="store_true", help="sorted input")
 a = ap.parse_args()
 L = ctypes.CDLL(lsd.LIB_PATH)
 n = 1 << 28
 host = mt19937_keys(n, 0) & np.uint32(a.mask)
 if a.heavy:
     host = np.where((host >> np.uint32(7)) % np.uint32(100) < np.uint32(a.heavy), np.uint32(0x80000001), host).astype(np.uint32)
+if a.sorted:
+    host = np.sort(host)
 master = lsd.to_device(host)
 stats = torch.zeros((1 << 17) * 16, dtype=torch.int64, device="cuda")
 L.lsdsort_debug_set_stats.argtypes = [ctypes.c_void_p]
