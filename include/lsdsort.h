@@ -382,7 +382,7 @@ LSDSORT_API int lsdsort_set_xcd_chunk(int chunk);
  * sorts and 1-bit digits always run every pass.  0 switches it off (every pass runs, as the reference's do). */
 LSDSORT_API int lsdsort_set_pass_skipping(int on);
 /* The hybrid form (lsdradixsort_amd/csrc/hybrid.hip, local_sort.hip; no reference counterpart -- its every pass goes through
- * global memory, .cu:844-905).  Sorts of 2^25 .. 9.6e8 keys or key/value pairs (uint32, int32, float32, either order) with 8- or
+ * global memory, .cu:844-905).  Sorts of 3.8e7 (pairs 2.2e7, 4-bit digits 2^24) .. 9.6e8 keys or key/value pairs (uint32, int32, float32, either order) with 8- or
  * 4-bit digits: bits 16-31 are sorted first by ordinary global passes (LSD order; two passes at 8-bit digits, four at 4-bit),
  * which leaves the array sorted by its top 16 bits; every bucket of equal top-15-bit value (top 14 bits while uniform keys still fit the local stage: up to about 2^27 items; top 16
  * from 4.8e8) is

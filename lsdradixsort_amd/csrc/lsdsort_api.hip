@@ -52,10 +52,14 @@ std::atomic<int> g_hybrid{[] {                                          // lsdso
 // stage room: 4096 .. 14648 keys per bucket, 2^14 .. 2^16 buckets (below, tens of thousands of workgroups of almost nothing cost more than the two passes
 // they replace; above, the largest bucket of even uniform keys nears the 16384-key capacity).  Whether it RUNS is decided on the
 // device from the exact bucket counts.
-// from 2^25 items (2^14 buckets of 2048 and more); keys alone at 8-bit digits from 3.8e7: below, their four passes are still ahead
-// (2^25 keys 101 against 95 Gkeys/s, 4e7 101 against 108; pairs 2^25 57 against 67 Gpairs/s)
-constexpr size_t kHybridMinKeys = (size_t)1 << 25;
-constexpr size_t kHybridMinKeysPlain8 = (size_t)38 * 1000 * 1000;
+// where the form starts to pay (2^14 buckets of 1024 .. 2400 keys there; measured with tools/size_perf.py): keys at 8-bit digits
+// from 3.8e7 (2^25 keys: 101 Gkeys/s in four passes against 95; 4e7: 101 against 108), pairs from 2.2e7 (2.4e7: 61 against 66
+// Gpairs/s; 2^24: 59 against 53), 4-bit digits from 2^24 (48 against 50 Gkeys/s; 2.4e7: 55 against 64)
+inline size_t hybrid_min_items(int radix_bits, bool pairs)
+{
+    if (radix_bits == 4) return (size_t)1 << 24;
+    return pairs ? (size_t)22 * 1000 * 1000 : (size_t)38 * 1000 * 1000;
+}
 constexpr size_t kHybridMaxKeys = (size_t)960 * 1000 * 1000;
 // The capacity of the local stage's launch over all buckets: the smallest variant that holds what uniform keys put into a bucket
 // (mean + 6 sigma); larger buckets go on the planner's list for the 16384-key variant.
@@ -436,7 +440,7 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
     // A typed sort gets a plan only where the hybrid form is tried (its kernels are told by the plan which form runs), and that plan
     // never skips a pass.
     const bool try_hybrid = algorithm == LSDSORT_ALGO_ONESWEEP && (radix_bits == 8 || radix_bits == 4) && !feed &&
-                            rank_method == lsd::kRankLdsAdd && n >= (radix_bits == 8 && !pairs ? kHybridMinKeysPlain8 : kHybridMinKeys) &&
+                            rank_method == lsd::kRankLdsAdd && n >= hybrid_min_items(radix_bits, pairs) &&
                             n <= kHybridMaxKeys &&
                             (n >> lsd::hybrid_bucket_bits(n, pairs)) <= lsd::kHybridMaxMeanBucket && shape->tile() == 32768 &&
                             g_hybrid.load(std::memory_order_relaxed);

@@ -58,14 +58,14 @@ def test_local_stage_alone(gpu):
                     assert np.array_equal(got_v[lo:hi], vals[lo:hi][order]), (low_bits, b, size, "payload order = stable order")
 
 
-@pytest.mark.parametrize("log2n,extra,radix", [(26, 999, 8), (27, 0, 8), (27, 12345, 8), (28, 777, 8), (29, 4242, 8), (25, 6445568, 8), (25, 77, 4), (26, 4097, 4), (27, 31, 4), (28, 5, 4),
+@pytest.mark.parametrize("log2n,extra,radix", [(26, 999, 8), (27, 0, 8), (27, 12345, 8), (28, 777, 8), (29, 4242, 8), (25, 6445568, 8), (25, 77, 4), (24, 99, 4), (26, 4097, 4), (27, 31, 4), (28, 5, 4),
                                                (29, 11, 4)])
 def test_hybrid_equals_torch_sort_and_the_four_pass_form(gpu, log2n, extra, radix):
     """radix 8: two global passes; radix 4 (BASELINE configs[1]'s digit width): four, their count fields derived by the planner."""
     import torch
 
     n = (1 << log2n) + extra
-    bb = {25: 14, 26: 14, 27: 14, 28: 15, 29: 16}[log2n]   # bucket = the top bb bits (lsd_kernels.hpp hybrid_bucket_bits, keys)
+    bb = {24: 14, 25: 14, 26: 14, 27: 14, 28: 15, 29: 16}[log2n]   # bucket = the top bb bits (lsd_kernels.hpp hybrid_bucket_bits, keys)
     sh, low = 32 - bb, (1 << (32 - bb)) - 1
     gen = torch.Generator(device="cuda")
     gen.manual_seed(4000 + log2n + extra)
@@ -107,7 +107,7 @@ def test_hybrid_equals_torch_sort_and_the_four_pass_form(gpu, log2n, extra, radi
     assert taken["half_zero"] == 0 and taken["small_range"] == 0 and taken["one_bucket_just_too_large"] == 0, taken
 
 
-@pytest.mark.parametrize("n", [(1 << 25) + 11, (1 << 26) + 77, (1 << 27) + 4321])
+@pytest.mark.parametrize("n", [24_000_000, (1 << 25) + 11, (1 << 26) + 77, (1 << 27) + 4321])
 def test_hybrid_pairs_are_stable(gpu, n):
     """Key/value pairs through the hybrid form (BASELINE configs[4]'s size): payload = input position, so the output must be
     torch's STABLE sort -- on keys the device takes (uniform; duplicates inside the buckets: 20 live bits below the bucket's) and on
@@ -146,13 +146,18 @@ def test_hybrid_pairs_are_stable(gpu, n):
 
 
 def test_hybrid_is_not_tried_outside_its_range(gpu):
-    """Below 2^25 items (3.8e7 for plain keys at 8-bit digits) and at 1- and 2-bit digits the ordinary form runs."""
+    """Below 3.8e7 keys at 8-bit digits (2.2e7 pairs, 2^24 items at 4-bit digits) and at 1- and 2-bit digits the ordinary form runs."""
     import torch
 
     n = (1 << 25) - 5
     d = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda")
     expect = torch.sort(_u64(d)).values
     tm = gpu.GPULSDRadixSortTimed(d, 8)
+    assert tm["hybrid"] == 0 and torch.equal(_u64(d), expect)
+    n = (1 << 24) - 5
+    d = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda")
+    expect = torch.sort(_u64(d)).values
+    tm = gpu.GPULSDRadixSortTimed(d, 4)
     assert tm["hybrid"] == 0 and torch.equal(_u64(d), expect)
     n = (1 << 27) + 3
     d = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda")
