@@ -68,7 +68,11 @@ int hybrid_small_cap(size_t n, bool pairs)
     static const bool tiny = [] { const char* e = getenv("LSDSORT_LOCAL_TINY"); return !(e && e[0] == '0'); }();   // experiment knob
     const double mean = (double)(n >> lsd::hybrid_bucket_bits(n, pairs));
     if (tiny && mean + 6.0 * std::sqrt(mean) <= (double)lsd::kLocalSortCapTiny) return lsd::kLocalSortCapTiny;
-    return pairs ? lsd::kLocalSortCapSmallPairs : lsd::kLocalSortCapSmall;
+    const int small = pairs ? lsd::kLocalSortCapSmallPairs : lsd::kLocalSortCapSmall;
+    // where most buckets of uniform keys are above the three-per-CU variant (the top of a bucket count's range: 6.7e8 .. 9.6e8
+    // keys) the launch over all buckets is the 16384-key variant itself and the planner's list stays empty
+    if (mean + 1.5 * std::sqrt(mean) > (double)small) return lsd::kLocalSortCap;
+    return small;
 }
 std::atomic<int> g_small_sort{[] {                                      // lsdsort_set_small_sort; LSDSORT_SMALL_SORT=0 starts it off
     const char* e = getenv("LSDSORT_SMALL_SORT");
@@ -579,7 +583,8 @@ int run_sort(uint32_t* d_keys, uint32_t* d_vals, void* d_ws, size_t ws_bytes, si
             if (ev) LSD_TRY(ev->mark());
             // buckets of up to 10240 keys (all of them on uniform keys of most sizes): three workgroups per CU; where uniform keys
             // stay under 5120 a bucket, four
-            lp.small_variant = hybrid_small_cap(n, pairs) == lsd::kLocalSortCapTiny ? 2u : 1u;
+            const int all_cap = hybrid_small_cap(n, pairs);
+            lp.small_variant = all_cap == lsd::kLocalSortCapTiny ? 2u : all_cap == lsd::kLocalSortCap ? 0u : 1u;
             lp.larger_elsewhere = 1;
             LSD_HIP(lsd::launch_local_sort(lp, stream));
             lp.small_variant = 0;     // the planner's list of larger ones (up to 16384 keys): two per CU, a grid of 512 walks the list
