@@ -743,8 +743,8 @@ static int sharded_step(lsdsort_comm* c, const uint32_t* d_keys_in, size_t n_loc
             SH_HIP(hipStreamWaitEvent(c->sorter, c->arrived[j], 0));
         }
         if (sub_size[j] == 0) SH_HIP(hipMemsetAsync(ws + L.sort_ws, 0, sizeof(uint32_t), sort_on));   // an empty sort never touches its fault word
-        // under the MSB partition the keys of sub-bucket j of rank r all carry the top `bits` bits (r, j): said so, the hybrid form
-        // plans its buckets below them (lsdsort_u32_device_prefixed; a hint -- the device checks)
+        // under the MSB partition the keys of sub-bucket j of rank r all carry the top `bits` bits (r, j): the hybrid form plans
+        // its buckets below such a prefix (hybrid.hip; the device finds it itself -- the argument says what this caller knows)
         SH_TRY(lsdsort_u32_device_prefixed(d_out + sub_begin, ws + L.sort_ws, L.sort_ws_bytes, (size_t)sub_size[j], radix_bits,
                                            partition == LSDSORT_PARTITION_MSB ? bits : 0, sort_on));
         SH_HIP(lsd::launch_keep_fault(sticky, reinterpret_cast<const uint32_t*>(ws + L.sort_ws), sort_on));
