@@ -12,7 +12,7 @@ lo_lg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 hi_lg = int(sys.argv[4]) if len(sys.argv) > 4 else 24
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 gen = torch.Generator(device="cuda"); gen.manual_seed(99)
-t0 = time.time(); done = 0
+t0 = time.time(); done = 0; last_note = t0
 while time.time() - t0 < budget_s and done < 200000:
     lg = rng.integers(lo_lg, hi_lg + 1)
     n = int(rng.integers(1 << max(lg - 1, 0), (1 << lg) + 1))
@@ -72,5 +72,8 @@ while time.time() - t0 < budget_s and done < 200000:
             assert torch.equal(k.to(torch.int64) & 0xFFFFFFFF, ref), (done, n, r, kind)
         assert lsd.lib().lsdsort_check_device(ws.data_ptr(), s.cuda_stream) == 0, (done, "fault word")
     done += 1
+    if time.time() - last_note > 60.0:          # a line a minute: the GPU box takes ten silent minutes for a hang
+        last_note = time.time()
+        print(f"... {done} sorts, {last_note - t0:.0f} s", flush=True)
 torch.cuda.synchronize()
 print(f"soak ok: {done} sorts in {time.time() - t0:.1f} s")
